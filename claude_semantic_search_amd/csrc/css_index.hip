@@ -1,0 +1,773 @@
+// css_index.hip -- exact flat index (IndexFlatIP / IndexFlatL2 semantics) for gfx950.
+//
+// Replaces, behind include/css_hip.h, the faiss calls of the reference's
+// HybridStorage: index creation (src/storage.py:252-258), add with the fused
+// row normalisation (src/storage.py:343-359) and the brute-force search
+// (src/storage.py:424-436).
+//
+// HBM layout: xb[cap][dpad] fp32 row-major, dpad = dim rounded up to 64 floats
+// (768 -> 768, i.e. 3072 B rows = 3 x 1 KiB wave loads), zero padded, plus
+// xnorm2[cap] (squared norms, used by the L2 MFMA path).  Capacity grows
+// geometrically or is reserved up front (css_index_reserve) so a 10M..80M row
+// shard is allocated once.
+//
+// Kernels (DESIGN.md has the rooflines):
+//   k_ingest_rows   one wave per row: optional synthetic generation, fused
+//                   x/(||x||+1e-8), zero pad, squared norm.           HBM bound
+//   k_scan_small    1..16 queries: 16 lanes per row (4 rows per wave
+//                   instruction, 256 B contiguous per row segment), VALU FMAs,
+//                   DPP row reduction, block-shared sorted top-k lists in LDS
+//                   with a grid-wide monotone threshold for pruning.  HBM bound
+//   k_merge_final   per query: merge the per-block lists into the final top-k.
+#include "css_common.h"
+#include "css_knn_kernels.h"
+#include "../../include/css_synth.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+#include <shared_mutex>
+#include <vector>
+
+using namespace css;
+
+struct css_index {
+    int dim = 0, dpad = 0, metric = 0, device = 0;
+    int64_t ntotal = 0, cap = 0, id_base = 0;
+    float* xb = nullptr;
+    float* xnorm2 = nullptr;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // reusable workspaces (grown on demand, guarded by ws_mu)
+    float* q_raw = nullptr;   size_t q_raw_cap = 0;     // floats
+    float* qpad = nullptr;    size_t qpad_cap = 0;      // floats
+    float* qnorm2 = nullptr;  size_t qnorm2_cap = 0;    // floats
+    int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
+    float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
+    float* out_d = nullptr;   int64_t* out_i = nullptr; size_t out_cap = 0;     // entries
+    float* stage = nullptr;   size_t stage_cap = 0;     // floats
+    std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
+    std::mutex ws_mu;      // workspaces + own stream are single-user
+};
+
+namespace {
+
+constexpr int kWaves = 4;  // waves per block in the scan kernels
+
+template <typename T>
+int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return CSS_OK;
+    size_t ncap = std::max(need, *cap * 2);
+    if (*p) CSS_HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void**)p, ncap * sizeof(T));
+    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(workspace)", __FILE__, __LINE__);
+    *cap = ncap;
+    return CSS_OK;
+}
+
+// ------------------------------------------------------------------ ingest
+// One wave per row.  SYNTH: value = css_synth_normal(seed, (first_row+row)*dim + c).
+template <bool SYNTH>
+__global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                     float* __restrict__ norm2, int64_t n, int dim, int dpad,
+                                                     int normalize, uint64_t seed, int64_t first_row) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* s = SYNTH ? nullptr : src + row * (int64_t)dim;
+    const uint64_t base = (uint64_t)((first_row + row) * (int64_t)dim);
+    float ss = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        float v = SYNTH ? css_synth_normal(seed, base + (uint64_t)c) : s[c];
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_allsum(ss);
+    // reference: x / (||x||_2 + 1e-8)  (src/storage.py:349-350, :426)
+    const float nrm = sqrtf(ss) + 1e-8f;
+    float* d = dst + row * (int64_t)dpad;
+    float s2 = 0.f;
+    for (int c = lane; c < dpad; c += 64) {
+        float v = 0.f;
+        if (c < dim) {
+            v = SYNTH ? css_synth_normal(seed, base + (uint64_t)c) : s[c];
+            if (normalize) v = v / nrm;
+        }
+        d[c] = v;
+        s2 = fmaf(v, v, s2);
+    }
+    s2 = wave_allsum(s2);
+    if (lane == 0 && norm2) norm2[row] = s2;
+}
+
+// ------------------------------------------------------------------ scan (small nq)
+// Block = 4 waves.  A wave instruction covers 4 rows: lane = 16*r + sub reads the
+// float4 at column 64*t + 4*sub of row r, so 16 lanes fetch 256 contiguous bytes.
+// Scores are "larger is better": IP -> dot, L2 -> -(sum (x-q)^2).
+// LDS: qs[NQ][dpad] | ls[NQ][k] | li[NQ][k] | lock[NQ]
+template <int NQ, int TT, int METRIC>
+__global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict__ xb, const float* __restrict__ qpad,
+                                                    int64_t ntotal, int T_rt, int k, int64_t groups_per_block,
+                                                    int* __restrict__ gthr, float* __restrict__ part_s,
+                                                    uint32_t* __restrict__ part_i, int nq_real) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = TT > 0 ? TT : T_rt;  // float4 steps of 16 lanes: dpad = 64*T
+    const int dpad = T * 64;
+    float* qs = reinterpret_cast<float*>(smem);
+    float* ls = qs + NQ * dpad;
+    uint32_t* li = reinterpret_cast<uint32_t*>(ls + NQ * k);
+    int* lock = reinterpret_cast<int*>(li + NQ * k);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, rsub = lane >> 4;
+
+    for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq_real ? qpad[i] : 0.f;
+    for (int i = tid; i < NQ * k; i += 256) {
+        ls[i] = -INFINITY;
+        li[i] = kInvalidRow;
+    }
+    if (tid < NQ) lock[tid] = 0;
+    __syncthreads();
+
+    const float4* qs4 = reinterpret_cast<const float4*>(qs);
+    const int64_t ngroups = (ntotal + 3) >> 2;
+    const int64_t g_begin = (int64_t)blockIdx.x * groups_per_block;
+    const int64_t g_end = min(g_begin + groups_per_block, ngroups);
+
+    float gcache[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) gcache[j] = -INFINITY;
+    int iter = 0;
+
+    for (int64_t g = g_begin + wave; g < g_end; g += kWaves, ++iter) {
+        // refresh the grid-wide thresholds now and then; kept at the top of the
+        // iteration so the FMA block below and its consumers stay in one basic block (stale values only prune less)
+        if ((iter & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                gcache[j] = key2f(__hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+
+        const int64_t row = g * 4 + rsub;
+        const bool valid = row < ntotal;
+        const int64_t rowc = valid ? row : ntotal - 1;
+        const float4* xr = xb + rowc * (int64_t)(T * 16) + sub;
+
+        float acc[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) acc[j] = 0.f;
+        // NQ > 1: keep the query fragments in LDS (re-read per row group) instead of
+        // letting LICM pin 12*NQ float4 in VGPRs, which would cost all the occupancy.
+        if constexpr (NQ > 1) asm volatile("" ::: "memory");
+
+        if constexpr (TT > 0) {
+            float4 xv[TT > 0 ? TT : 1];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) xv[t] = xr[t * 16];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const float4 q = qs4[j * (TT * 16) + t * 16 + sub];
+                    if constexpr (METRIC == CSS_METRIC_IP) {
+                        acc[j] = fmaf(xv[t].x, q.x, acc[j]);
+                        acc[j] = fmaf(xv[t].y, q.y, acc[j]);
+                        acc[j] = fmaf(xv[t].z, q.z, acc[j]);
+                        acc[j] = fmaf(xv[t].w, q.w, acc[j]);
+                    } else {
+                        float dx = xv[t].x - q.x, dy = xv[t].y - q.y, dz = xv[t].z - q.z, dw = xv[t].w - q.w;
+                        acc[j] = fmaf(dx, dx, acc[j]);
+                        acc[j] = fmaf(dy, dy, acc[j]);
+                        acc[j] = fmaf(dz, dz, acc[j]);
+                        acc[j] = fmaf(dw, dw, acc[j]);
+                    }
+                }
+                // fence the scheduler per column step: otherwise all 12*NQ LDS reads are
+                // clustered up front and the kernel spills
+                if constexpr (NQ > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                const float4 x = xr[t * 16];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const float4 q = qs4[j * (T * 16) + t * 16 + sub];
+                    if constexpr (METRIC == CSS_METRIC_IP) {
+                        acc[j] = fmaf(x.x, q.x, acc[j]);
+                        acc[j] = fmaf(x.y, q.y, acc[j]);
+                        acc[j] = fmaf(x.z, q.z, acc[j]);
+                        acc[j] = fmaf(x.w, q.w, acc[j]);
+                    } else {
+                        float dx = x.x - q.x, dy = x.y - q.y, dz = x.z - q.z, dw = x.w - q.w;
+                        acc[j] = fmaf(dx, dx, acc[j]);
+                        acc[j] = fmaf(dy, dy, acc[j]);
+                        acc[j] = fmaf(dz, dz, acc[j]);
+                        acc[j] = fmaf(dw, dw, acc[j]);
+                    }
+                }
+            }
+        }
+
+        // All scores and pass flags are formed in this basic block (one combined
+        // ballot), so the FMA chains above cannot be sunk behind the rare slow path.
+        float sc[NQ];
+        bool anyp = false;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            float s = row16_allsum(acc[j]);
+            if constexpr (METRIC == CSS_METRIC_L2) s = -s;
+            sc[j] = s;
+            const float lthr = ls[j * k + (k - 1)];
+            // non-strict: an equal score with a lower row id must still reach the comparator
+            anyp |= (s >= lthr) & (s >= gcache[j]) & (j < nq_real);  // '&': no short-circuit branches
+        }
+        if (__ballot(anyp && valid && sub == 0) == 0ull) continue;
+
+        for (int j = 0; j < nq_real; ++j) {
+            float s = sc[0];
+#pragma unroll
+            for (int u = 1; u < NQ; ++u) s = j == u ? sc[u] : s;
+            const float lthr = ls[j * k + (k - 1)];
+            const float gj = key2f(__hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const bool pass = valid && sub == 0 && s >= lthr && s >= gj;
+            unsigned long long m = __ballot(pass);
+            if (m == 0ull) continue;
+            // slow path: serialise on the block-shared list of query j
+            if (lane == 0) {
+                while (atomicCAS(&lock[j], 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bool changed = false;
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float cs = __shfl(s, l);
+                const uint32_t cid = (uint32_t)(g * 4 + (l >> 4));
+                changed |= wave_insert<uint32_t>(ls + j * k, li + j * k, k, cs, cid, lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const float kth = ls[j * k + (k - 1)];
+            if (lane == 0) {
+                atomicExch(&lock[j], 0);
+                if (changed && kth > gj) atomicMax(&gthr[j], f2key(kth));
+            }
+        }
+    }
+    __syncthreads();
+    // part layout: [q][block][k]
+    const int G = gridDim.x;
+    for (int i = tid; i < nq_real * k; i += 256) {
+        const int j = i / k, p = i - j * k;
+        const size_t o = ((size_t)j * G + blockIdx.x) * k + p;
+        part_s[o] = ls[i];
+        part_i[o] = li[i];
+    }
+}
+
+// ------------------------------------------------------------------ final merge
+// One block per query.  Scans the G*k per-block entries in rounds of CAP,
+// appends the ones that can still matter to an LDS buffer, wave 0 inserts them.
+constexpr int kMergeCap = 2048;
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ part_s,
+                                                     const uint32_t* __restrict__ part_i, int G, int k,
+                                                     const int* __restrict__ gthr, const float* __restrict__ qnorm2,
+                                                     int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
+                                                     int l2_expanded) {
+    __shared__ float fs[CSS_MAX_K];
+    __shared__ uint32_t fi[CSS_MAX_K];
+    __shared__ float cs[kMergeCap];
+    __shared__ uint32_t ci[kMergeCap];
+    __shared__ int cnt;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)q * G * k;
+    const int entries = G * k;
+    const float g = key2f(gthr[q]);
+    for (int i = tid; i < k; i += 256) {
+        fs[i] = -INFINITY;
+        fi[i] = kInvalidRow;
+    }
+    for (int start = 0; start < entries; start += kMergeCap) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        const float kth = fs[k - 1];
+        const uint32_t kid = fi[k - 1];
+        for (int e = start + tid; e < min(start + kMergeCap, entries); e += 256) {
+            const float s = part_s[base + e];
+            const uint32_t id = part_i[base + e];
+            if (id != kInvalidRow && s >= g && better<uint32_t>(s, id, kth, kid)) {
+                const int p = atomicAdd(&cnt, 1);
+                cs[p] = s;
+                ci[p] = id;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int n = cnt;
+            for (int c = 0; c < n; ++c) wave_insert<uint32_t>(fs, fi, k, cs[c], ci[c], lane);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < k; i += 256) {
+        const uint32_t id = fi[i];
+        float s = fs[i];
+        float d;
+        if (METRIC == CSS_METRIC_IP) {
+            d = id == kInvalidRow ? -FLT_MAX : s;
+        } else {
+            // scan kernels produce s = -(squared distance) (direct form) or, in the
+            // expanded MFMA form, s = 2 x.q - ||x||^2 (||q||^2 added here)
+            if (id == kInvalidRow) d = FLT_MAX;
+            else if (l2_expanded) d = fmaxf(0.f, qnorm2[q] - s);
+            else d = -s;
+        }
+        D[(size_t)q * k + i] = d;
+        I[(size_t)q * k + i] = id == kInvalidRow ? (int64_t)-1 : id_base + (int64_t)id;
+    }
+}
+
+// Merge of per-shard final results with global int64 ids (multi-GPU exchange).
+template <int METRIC>
+__global__ __launch_bounds__(64) void k_merge_parts(const float* __restrict__ Dp, const int64_t* __restrict__ Ip,
+                                                    int nparts, int64_t nq, int k, float* __restrict__ D,
+                                                    int64_t* __restrict__ I) {
+    __shared__ float fs[CSS_MAX_K];
+    __shared__ int64_t fi[CSS_MAX_K];
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < k; i += 64) {
+        fs[i] = -INFINITY;
+        fi[i] = INT64_MAX;
+    }
+    for (int p = 0; p < nparts; ++p)
+        for (int j = 0; j < k; ++j) {
+            const size_t o = ((size_t)p * nq + q) * k + j;
+            const int64_t id = Ip[o];
+            if (id < 0) continue;  // wave uniform
+            float s = Dp[o];
+            if (METRIC == CSS_METRIC_L2) s = -s;
+            wave_insert<int64_t>(fs, fi, k, s, id, lane);
+        }
+    for (int i = lane; i < k; i += 64) {
+        const int64_t id = fi[i];
+        const bool empty = id == INT64_MAX;
+        float s = fs[i];
+        D[q * k + i] = METRIC == CSS_METRIC_IP ? (empty ? -FLT_MAX : s) : (empty ? FLT_MAX : -s);
+        I[q * k + i] = empty ? -1 : id;
+    }
+}
+
+__global__ void k_fill_int(int* p, int n, int v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------- host side
+int ensure_capacity(css_index* ix, int64_t need) {
+    if (need <= ix->cap) return CSS_OK;
+    int64_t ncap = std::max<int64_t>(need, ix->cap + ix->cap / 2);
+    ncap = std::max<int64_t>(ncap, 1024);
+    float* nxb = nullptr;
+    float* nn2 = nullptr;
+    hipError_t e = hipMalloc((void**)&nxb, (size_t)ncap * ix->dpad * sizeof(float));
+    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(index rows)", __FILE__, __LINE__);
+    e = hipMalloc((void**)&nn2, (size_t)ncap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nxb);
+        return css::hip_fail(e, "hipMalloc(index norms)", __FILE__, __LINE__);
+    }
+    if (ix->ntotal > 0) {
+        CSS_HIP_TRY(hipMemcpyAsync(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float),
+                                   hipMemcpyDeviceToDevice, ix->stream));
+        CSS_HIP_TRY(hipMemcpyAsync(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
+                                   ix->stream));
+        CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    if (ix->xb) CSS_HIP_TRY(hipFree(ix->xb));
+    if (ix->xnorm2) CSS_HIP_TRY(hipFree(ix->xnorm2));
+    ix->xb = nxb;
+    ix->xnorm2 = nn2;
+    ix->cap = ncap;
+    return CSS_OK;
+}
+
+int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool synth, uint64_t seed,
+           int64_t first_row, hipStream_t st) {
+    const int64_t blocks = (n + 3) / 4;
+    CSS_REQUIRE(blocks < (1ll << 31), "ingest: too many rows in one call");
+    float* dst = ix->xb + (size_t)ix->ntotal * ix->dpad;
+    float* n2 = ix->xnorm2 + ix->ntotal;
+    if (synth)
+        hipLaunchKernelGGL(k_ingest_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, nullptr, dst, n2, n,
+                           ix->dim, ix->dpad, normalize, seed, first_row);
+    else
+        hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x_dev, dst, n2, n,
+                           ix->dim, ix->dpad, normalize, 0ull, 0ll);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+template <int NQ, int TT, int METRIC>
+int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, int G,
+                        int64_t groups_per_block, hipStream_t st) {
+    const int T = ix->dpad / 64;
+    const size_t lds = (size_t)NQ * ix->dpad * 4 + (size_t)NQ * k * 8 + NQ * 4;
+    auto kern = k_scan_small<NQ, TT, METRIC>;
+    if (lds > 48 * 1024)
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps("knn_scan_small", st);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, (const float4*)ix->xb, qpad, ix->ntotal, T, k,
+                       groups_per_block, gthr, ix->part_s, ix->part_i, nq_real);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+template <int NQ>
+int launch_scan_small_nq(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, int G,
+                         int64_t gpb, hipStream_t st) {
+    const bool ip = ix->metric == CSS_METRIC_IP;
+    if (ix->dpad == 768) {
+        return ip ? launch_scan_small_t<NQ, 12, CSS_METRIC_IP>(ix, qpad, nq_real, k, gthr, G, gpb, st)
+                  : launch_scan_small_t<NQ, 12, CSS_METRIC_L2>(ix, qpad, nq_real, k, gthr, G, gpb, st);
+    }
+    return ip ? launch_scan_small_t<NQ, 0, CSS_METRIC_IP>(ix, qpad, nq_real, k, gthr, G, gpb, st)
+              : launch_scan_small_t<NQ, 0, CSS_METRIC_L2>(ix, qpad, nq_real, k, gthr, G, gpb, st);
+}
+
+int grow_part(css_index* ix, size_t entries) {
+    if (entries <= ix->part_cap) return CSS_OK;
+    size_t ncap = std::max(entries, ix->part_cap * 2);
+    if (ix->part_s) CSS_HIP_TRY(hipFree(ix->part_s));
+    if (ix->part_i) CSS_HIP_TRY(hipFree(ix->part_i));
+    ix->part_s = nullptr;
+    ix->part_i = nullptr;
+    ix->part_cap = 0;
+    hipError_t e = hipMalloc((void**)&ix->part_s, ncap * sizeof(float));
+    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(part_s)", __FILE__, __LINE__);
+    e = hipMalloc((void**)&ix->part_i, ncap * sizeof(uint32_t));
+    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(part_i)", __FILE__, __LINE__);
+    ix->part_cap = ncap;
+    return CSS_OK;
+}
+
+inline int host_f2key(float f) {
+    int i;
+    memcpy(&i, &f, 4);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+
+// Queries [q0, q0+nqc) (nqc <= 16) against the whole index, results to D/I rows q0...
+int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb, float* D_dev, int64_t* I_dev,
+                       hipStream_t st) {
+    int* gthr = ix->gthr + q0;
+    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(64), 0, st, gthr, nqc, host_f2key(-INFINITY));
+    CSS_LAUNCH_CHECK();
+    const float* qp = ix->qpad + (size_t)q0 * ix->dpad;
+    int rc;
+    if (nqc <= 1) rc = launch_scan_small_nq<1>(ix, qp, nqc, k, gthr, G, gpb, st);
+    else if (nqc <= 2) rc = launch_scan_small_nq<2>(ix, qp, nqc, k, gthr, G, gpb, st);
+    else if (nqc <= 8)  // (an NQ=4 instantiation spills under hipcc 7.2; 3..8 share NQ=8)
+         rc = launch_scan_small_nq<8>(ix, qp, nqc, k, gthr, G, gpb, st);
+    else rc = launch_scan_small_nq<16>(ix, qp, nqc, k, gthr, G, gpb, st);
+    if (rc != CSS_OK) return rc;
+    {
+        ProfScope ps("knn_merge", st);
+        if (ix->metric == CSS_METRIC_IP)
+            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_IP>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, G,
+                               k, gthr, ix->qnorm2 + q0, ix->id_base, D_dev + (size_t)q0 * k,
+                               I_dev + (size_t)q0 * k, 0);
+        else
+            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_L2>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, G,
+                               k, gthr, ix->qnorm2 + q0, ix->id_base, D_dev + (size_t)q0 * k,
+                               I_dev + (size_t)q0 * k, 0);
+        CSS_LAUNCH_CHECK();
+    }
+    return CSS_OK;
+}
+
+// q_dev: raw [nq, dim] device queries.  Caller holds ws_mu and a shared lock on mu.
+int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
+                      int64_t* I_dev, hipStream_t st) {
+    CSS_REQUIRE(k >= 1 && k <= CSS_MAX_K, "css_index_search: k=%d outside [1, %d]", k, CSS_MAX_K);
+    CSS_REQUIRE(nq >= 0 && nq < (1 << 24), "css_index_search: nq=%lld out of range", (long long)nq);
+    if (nq == 0) return CSS_OK;
+    int rc;
+    if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 128) * ix->dpad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 128)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 128)) != CSS_OK) return rc;
+    // query prep: same row kernel as ingest (normalise, zero pad, squared norm)
+    {
+        const int64_t blocks = (nq + 3) / 4;
+        hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, q_dev, ix->qpad,
+                           ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll);
+        CSS_LAUNCH_CHECK();
+    }
+    if (ix->ntotal == 0) {
+        // nothing to scan: pad (cannot be reached through the reference: src/storage.py:421-422)
+        std::vector<float> hd((size_t)nq * k, ix->metric == CSS_METRIC_IP ? -FLT_MAX : FLT_MAX);
+        std::vector<int64_t> hi((size_t)nq * k, -1);
+        CSS_HIP_TRY(hipMemcpyAsync(D_dev, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, st));
+        CSS_HIP_TRY(hipMemcpyAsync(I_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, st));
+        CSS_HIP_TRY(hipStreamSynchronize(st));
+        return CSS_OK;
+    }
+    // queries per sweep: keep the block's LDS (queries + lists) <= 64 KiB so >= 2 blocks fit a CU
+    int nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 4));
+    CSS_REQUIRE(nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
+    // enough blocks to fill the chip (8 per CU) but at least ~64 row groups of work each
+    const int64_t ngroups = (ix->ntotal + 3) / 4;
+    int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ix->num_cus * 8, (ngroups + 63) / 64));
+    const int64_t gpb = (ngroups + G - 1) / G;
+    G = (ngroups + gpb - 1) / gpb;
+    if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
+    for (int64_t q0 = 0; q0 < nq; q0 += nq_sweep) {
+        const int nqc = (int)std::min<int64_t>(nq_sweep, nq - q0);
+        if ((rc = search_chunk_small(ix, (int)q0, nqc, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;
+    }
+    return CSS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int css_index_create(int dim, int metric, int device, css_index** out) {
+    CSS_REQUIRE(out != nullptr, "css_index_create: out is NULL");
+    CSS_REQUIRE(dim >= 1 && dim <= 8192, "css_index_create: dim=%d outside [1, 8192]", dim);
+    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "css_index_create: unknown metric %d", metric);
+    int rc = css::check_device(device);
+    if (rc != CSS_OK) return rc;
+    DeviceGuard g(device);
+    css_index* ix = new css_index();
+    ix->dim = dim;
+    ix->dpad = (dim + 63) / 64 * 64;
+    ix->metric = metric;
+    ix->device = device;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) ix->num_cus = p.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ix;
+        return css::hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    *out = ix;
+    return CSS_OK;
+}
+
+int css_index_free(css_index* ix) {
+    if (!ix) return CSS_OK;
+    DeviceGuard g(ix->device);
+    (void)hipStreamSynchronize(ix->stream);
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr,
+                    ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(ix->stream);
+    delete ix;
+    return CSS_OK;
+}
+
+int css_index_reset(css_index* ix) {
+    CSS_REQUIRE(ix, "css_index_reset: NULL index");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    ix->ntotal = 0;
+    return CSS_OK;
+}
+
+int css_index_reserve(css_index* ix, int64_t n) {
+    CSS_REQUIRE(ix && n >= 0, "css_index_reserve: bad argument");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (n <= ix->cap) return CSS_OK;
+    // exact-size allocation (no 1.5x growth): a 245 GB shard must not over-allocate
+    float* nxb = nullptr;
+    float* nn2 = nullptr;
+    hipError_t e = hipMalloc((void**)&nxb, (size_t)n * ix->dpad * sizeof(float));
+    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(index rows)", __FILE__, __LINE__);
+    e = hipMalloc((void**)&nn2, (size_t)n * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nxb);
+        return css::hip_fail(e, "hipMalloc(index norms)", __FILE__, __LINE__);
+    }
+    if (ix->ntotal > 0) {
+        CSS_HIP_TRY(hipMemcpy(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float), hipMemcpyDeviceToDevice));
+        CSS_HIP_TRY(hipMemcpy(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (ix->xb) CSS_HIP_TRY(hipFree(ix->xb));
+    if (ix->xnorm2) CSS_HIP_TRY(hipFree(ix->xnorm2));
+    ix->xb = nxb;
+    ix->xnorm2 = nn2;
+    ix->cap = n;
+    return CSS_OK;
+}
+
+int css_index_ntotal(const css_index* ix, int64_t* n) {
+    CSS_REQUIRE(ix && n, "css_index_ntotal: NULL argument");
+    *n = ix->ntotal;
+    return CSS_OK;
+}
+
+int css_index_dim(const css_index* ix, int* dim) {
+    CSS_REQUIRE(ix && dim, "css_index_dim: NULL argument");
+    *dim = ix->dim;
+    return CSS_OK;
+}
+
+int css_index_metric(const css_index* ix, int* metric) {
+    CSS_REQUIRE(ix && metric, "css_index_metric: NULL argument");
+    *metric = ix->metric;
+    return CSS_OK;
+}
+
+int css_index_device(const css_index* ix, int* device) {
+    CSS_REQUIRE(ix && device, "css_index_device: NULL argument");
+    *device = ix->device;
+    return CSS_OK;
+}
+
+int css_index_set_id_base(css_index* ix, int64_t base) {
+    CSS_REQUIRE(ix, "css_index_set_id_base: NULL index");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    ix->id_base = base;
+    return CSS_OK;
+}
+
+int css_index_add(css_index* ix, const float* x_host, int64_t n, int normalize) {
+    CSS_REQUIRE(ix, "css_index_add: NULL index");
+    CSS_REQUIRE(n >= 0, "css_index_add: n < 0");
+    if (n == 0) return CSS_OK;
+    CSS_REQUIRE(x_host, "css_index_add: x is NULL");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);
+    DeviceGuard g(ix->device);
+    int rc = ensure_capacity(ix, ix->ntotal + n);
+    if (rc != CSS_OK) return rc;
+    // stage through a bounded device buffer so huge adds do not double the footprint
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix->dim * 4));
+    if ((rc = grow(&ix->stage, &ix->stage_cap, (size_t)std::min(n, chunk) * ix->dim)) != CSS_OK) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t m = std::min(chunk, n - r0);
+        CSS_HIP_TRY(hipMemcpyAsync(ix->stage, x_host + (size_t)r0 * ix->dim, (size_t)m * ix->dim * 4,
+                                   hipMemcpyHostToDevice, ix->stream));
+        if ((rc = ingest(ix, ix->stage, m, normalize, false, 0, 0, ix->stream)) != CSS_OK) return rc;
+        CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
+        ix->ntotal += m;
+    }
+    return CSS_OK;
+}
+
+int css_index_add_dev(css_index* ix, const float* x_dev, int64_t n, int normalize, void* stream) {
+    CSS_REQUIRE(ix, "css_index_add_dev: NULL index");
+    CSS_REQUIRE(n >= 0, "css_index_add_dev: n < 0");
+    if (n == 0) return CSS_OK;
+    CSS_REQUIRE(x_dev, "css_index_add_dev: x is NULL");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = ensure_capacity(ix, ix->ntotal + n);
+    if (rc != CSS_OK) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += (1ll << 30)) {
+        const int64_t m = std::min<int64_t>(1ll << 30, n - r0);
+        if ((rc = ingest(ix, x_dev + (size_t)r0 * ix->dim, m, normalize, false, 0, 0, (hipStream_t)stream)) != CSS_OK)
+            return rc;
+        ix->ntotal += m;
+    }
+    return CSS_OK;
+}
+
+int css_index_add_synthetic(css_index* ix, int64_t n, uint64_t seed, int64_t first_row, int normalize,
+                            void* stream) {
+    CSS_REQUIRE(ix, "css_index_add_synthetic: NULL index");
+    CSS_REQUIRE(n >= 0, "css_index_add_synthetic: n < 0");
+    if (n == 0) return CSS_OK;
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = ensure_capacity(ix, ix->ntotal + n);
+    if (rc != CSS_OK) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += (1ll << 30)) {
+        const int64_t m = std::min<int64_t>(1ll << 30, n - r0);
+        if ((rc = ingest(ix, nullptr, m, normalize, true, seed, first_row + r0, (hipStream_t)stream)) != CSS_OK)
+            return rc;
+        ix->ntotal += m;
+    }
+    return CSS_OK;
+}
+
+int css_index_export(const css_index* cix, int64_t row0, int64_t n, float* x_out_host) {
+    css_index* ix = const_cast<css_index*>(cix);
+    CSS_REQUIRE(ix && x_out_host, "css_index_export: NULL argument");
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    CSS_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, "css_index_export: rows [%lld, %lld) outside [0, %lld)",
+                (long long)row0, (long long)(row0 + n), (long long)ix->ntotal);
+    if (n == 0) return CSS_OK;
+    DeviceGuard g(ix->device);
+    CSS_HIP_TRY(hipMemcpy2D(x_out_host, (size_t)ix->dim * 4, ix->xb + (size_t)row0 * ix->dpad, (size_t)ix->dpad * 4,
+                            (size_t)ix->dim * 4, (size_t)n, hipMemcpyDeviceToHost));
+    return CSS_OK;
+}
+
+int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
+                         int64_t* I_dev, void* stream) {
+    CSS_REQUIRE(ix, "css_index_search_dev: NULL index");
+    CSS_REQUIRE(nq == 0 || (q_dev && D_dev && I_dev), "css_index_search_dev: NULL buffer");
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);
+    DeviceGuard g(ix->device);
+    return search_dev_locked(ix, q_dev, nq, k, normalize_q, D_dev, I_dev, (hipStream_t)stream);
+}
+
+int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q, float* D_host,
+                     int64_t* I_host) {
+    CSS_REQUIRE(ix, "css_index_search: NULL index");
+    CSS_REQUIRE(nq >= 0, "css_index_search: nq < 0");
+    if (nq == 0) return CSS_OK;
+    CSS_REQUIRE(q_host && D_host && I_host, "css_index_search: NULL buffer");
+    CSS_REQUIRE(k >= 1 && k <= CSS_MAX_K, "css_index_search: k=%d outside [1, %d]", k, CSS_MAX_K);
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);
+    DeviceGuard g(ix->device);
+    int rc;
+    if ((rc = grow(&ix->q_raw, &ix->q_raw_cap, (size_t)nq * ix->dim)) != CSS_OK) return rc;
+    {
+        size_t need = (size_t)nq * k;
+        if (need > ix->out_cap) {
+            if (ix->out_d) CSS_HIP_TRY(hipFree(ix->out_d));
+            if (ix->out_i) CSS_HIP_TRY(hipFree(ix->out_i));
+            ix->out_d = nullptr;
+            ix->out_i = nullptr;
+            ix->out_cap = 0;
+            CSS_HIP_TRY(hipMalloc((void**)&ix->out_d, need * sizeof(float)));
+            CSS_HIP_TRY(hipMalloc((void**)&ix->out_i, need * sizeof(int64_t)));
+            ix->out_cap = need;
+        }
+    }
+    CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, q_host, (size_t)nq * ix->dim * 4, hipMemcpyHostToDevice, ix->stream));
+    if ((rc = search_dev_locked(ix, ix->q_raw, nq, k, normalize_q, ix->out_d, ix->out_i, ix->stream)) != CSS_OK)
+        return rc;
+    CSS_HIP_TRY(hipMemcpyAsync(D_host, ix->out_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    CSS_HIP_TRY(hipMemcpyAsync(I_host, ix->out_i, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
+    return CSS_OK;
+}
+
+int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t nq, int k, int metric, float* D,
+                       int64_t* I, int device, void* stream) {
+    CSS_REQUIRE(Dp && Ip && D && I, "css_merge_topk_dev: NULL buffer");
+    CSS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= CSS_MAX_K, "css_merge_topk_dev: bad sizes");
+    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "css_merge_topk_dev: unknown metric");
+    int rc = css::check_device(device);
+    if (rc != CSS_OK) return rc;
+    if (nq == 0) return CSS_OK;
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("knn_merge_parts", st);
+    if (metric == CSS_METRIC_IP)
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, nq, k, D, I);
+    else
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, nq, k, D, I);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+"""Flat exact index on the MI355X, duck-typing what the reference uses of faiss.
+
+The reference touches exactly these faiss members: the classes
+``IndexFlatIP`` / ``IndexFlatL2`` (``src/storage.py:256-258``), ``index.ntotal``
+(``:358``, ``:421``), ``index.add(x)`` (``:359``), ``index.search(q, k)``
+(``:436``), ``faiss.read_index`` / ``write_index`` (``:306``, ``:879-884``,
+``:895``, ``:913``) and the device toggles ``index_cpu_to_gpu`` /
+``index_gpu_to_cpu`` / ``StandardGpuResources`` / ``get_num_gpus`` (``:274-296``,
+``src/gpu_utils.py:117-118``).  This module provides the same names over
+``libcss_hip.so``; the index always lives in HBM (there is no CPU index).
+"""
+from __future__ import annotations
+
+import ctypes
+import struct
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+METRIC_INNER_PRODUCT = nat.METRIC_IP
+METRIC_L2 = nat.METRIC_L2
+
+
+def _as_f32_2d(x, d: int, what: str) -> np.ndarray:
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != d:
+        raise ValueError(f"{what}: expected shape (n, {d}), got {tuple(np.shape(x))}")
+    return a
+
+
+class IndexFlat:
+    """Exact brute-force index in HBM (``faiss.IndexFlat`` semantics)."""
+
+    def __init__(self, d: int, metric: int = METRIC_INNER_PRODUCT, device: int = 0):
+        self.d = int(d)
+        self.metric_type = int(metric)
+        self.device = int(device)
+        self.is_trained = True
+        h = ctypes.c_void_p()
+        nat.check(nat.lib().css_index_create(self.d, self.metric_type, self.device, ctypes.byref(h)))
+        self._h: Optional[ctypes.c_void_p] = h
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None:
+            nat.lib().css_index_free(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._h is None:
+            raise RuntimeError("index has been freed")
+        return self._h
+
+    # -- faiss surface ----------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        n = ctypes.c_int64(0)
+        nat.check(nat.lib().css_index_ntotal(self._handle(), ctypes.byref(n)))
+        return int(n.value)
+
+    def reset(self) -> None:
+        nat.check(nat.lib().css_index_reset(self._handle()))
+
+    def reserve(self, n: int) -> None:
+        nat.check(nat.lib().css_index_reserve(self._handle(), int(n)))
+
+    def add(self, x, normalize: bool = False) -> None:
+        """Append rows; ids are ``ntotal .. ntotal+n-1`` (``src/storage.py:358-365``).
+        ``normalize=True`` fuses the reference's ``x / (||x|| + 1e-8)``
+        (``src/storage.py:347-350``) into the ingest kernel."""
+        a = _as_f32_2d(x, self.d, "add")
+        if a.shape[0] == 0:
+            return
+        nat.check(nat.lib().css_index_add(self._handle(), a.ctypes.data, a.shape[0], 1 if normalize else 0))
+
+    def add_synthetic(self, n: int, seed: int, first_row: int = 0, normalize: bool = True, stream: int = 0) -> None:
+        nat.check(nat.lib().css_index_add_synthetic(self._handle(), int(n), ctypes.c_uint64(seed), int(first_row),
+                                                    1 if normalize else 0, ctypes.c_void_p(stream)))
+
+    def search(self, q, k: int, normalize: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """``(D[nq,k] float32, I[nq,k] int64)``; IP descending, L2 ascending squared
+        distances, ``-1`` padded (``src/storage.py:436``)."""
+        a = _as_f32_2d(q, self.d, "search")
+        k = int(k)
+        if k < 1 or k > nat.MAX_K:
+            raise ValueError(f"k={k} outside [1, {nat.MAX_K}]")
+        nq = a.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        if nq:
+            nat.check(nat.lib().css_index_search(self._handle(), a.ctypes.data, nq, k, 1 if normalize else 0,
+                                                 D.ctypes.data, I.ctypes.data))
+        return D, I
+
+    def search_dev(self, q_ptr: int, nq: int, k: int, D_ptr: int, I_ptr: int, stream: int = 0,
+                   normalize: bool = False) -> None:
+        """Device-pointer twin: ``q_ptr``/``D_ptr``/``I_ptr`` are device addresses
+        (e.g. ``tensor.data_ptr()``), enqueued on ``stream`` (a ``hipStream_t``)."""
+        nat.check(nat.lib().css_index_search_dev(self._handle(), ctypes.c_void_p(q_ptr), int(nq), int(k),
+                                                 1 if normalize else 0, ctypes.c_void_p(D_ptr),
+                                                 ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
+
+    def set_id_base(self, base: int) -> None:
+        nat.check(nat.lib().css_index_set_id_base(self._handle(), int(base)))
+
+    def reconstruct_n(self, row0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        if n is None:
+            n = self.ntotal - row0
+        out = np.empty((int(n), self.d), dtype=np.float32)
+        if n:
+            nat.check(nat.lib().css_index_export(self._handle(), int(row0), int(n), out.ctypes.data))
+        return out
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        return self.reconstruct_n(int(i), 1)[0]
+
+
+class IndexFlatIP(IndexFlat):
+    def __init__(self, d: int, device: int = 0):
+        super().__init__(d, METRIC_INNER_PRODUCT, device)
+
+
+class IndexFlatL2(IndexFlat):
+    def __init__(self, d: int, device: int = 0):
+        super().__init__(d, METRIC_L2, device)
+
+
+# ---------------------------------------------------------------------------
+# faiss module-level seams
+# ---------------------------------------------------------------------------
+def get_num_gpus() -> int:
+    return nat.device_count()
+
+
+class StandardGpuResources:
+    """Placeholder for ``faiss.StandardGpuResources`` (``src/storage.py:274``):
+    libcss_hip owns its streams and workspaces per index."""
+
+    def __init__(self):
+        if nat.device_count() <= 0:
+            raise RuntimeError("no HIP device")
+
+
+def index_cpu_to_gpu(resources, device: int, index: IndexFlat) -> IndexFlat:
+    """The index already lives in HBM; moving between devices copies the rows."""
+    if index.device == int(device):
+        return index
+    out = IndexFlat(index.d, index.metric_type, int(device))
+    if index.ntotal:
+        out.add(index.reconstruct_n(0, index.ntotal))
+    return out
+
+
+def index_gpu_to_cpu(index: IndexFlat) -> IndexFlat:
+    return index
+
+
+# On-disk format of faiss' IndexFlat ([from-knowledge], not
+# verifiable offline because faiss is not installed -- cross-compat untested):
+#   fourcc "IxFI" (IP) / "IxF2" (L2) | int32 d | int64 ntotal | int64 dummy (1<<20)
+#   | int64 dummy (1<<20) | uint8 is_trained | int32 metric_type
+#   | uint64 n_floats | n_floats * float32 (row-major)
+_FOURCC = {METRIC_INNER_PRODUCT: b"IxFI", METRIC_L2: b"IxF2"}
+_FAISS_METRIC = {METRIC_INNER_PRODUCT: 0, METRIC_L2: 1}
+
+
+def write_index(index: IndexFlat, path: str, chunk_rows: int = 1 << 18) -> None:
+    n = index.ntotal
+    with open(path, "wb") as f:
+        f.write(_FOURCC[index.metric_type])
+        f.write(struct.pack("<i", index.d))
+        f.write(struct.pack("<q", n))
+        f.write(struct.pack("<q", 1 << 20))
+        f.write(struct.pack("<q", 1 << 20))
+        f.write(struct.pack("<B", 1))
+        f.write(struct.pack("<i", _FAISS_METRIC[index.metric_type]))
+        f.write(struct.pack("<Q", n * index.d))
+        for r0 in range(0, n, chunk_rows):
+            m = min(chunk_rows, n - r0)
+            f.write(index.reconstruct_n(r0, m).tobytes())
+
+
+def read_index(path: str, device: int = 0, chunk_rows: int = 1 << 18) -> IndexFlat:
+    with open(path, "rb") as f:
+        fourcc = f.read(4)
+        metric = {v: k for k, v in _FOURCC.items()}.get(fourcc)
+        if metric is None:
+            raise RuntimeError(f"unsupported index file (fourcc {fourcc!r}); only IndexFlatIP/L2 are implemented")
+        (d,) = struct.unpack("<i", f.read(4))
+        (n,) = struct.unpack("<q", f.read(8))
+        f.read(16)
+        f.read(1)
+        f.read(4)
+        (nfl,) = struct.unpack("<Q", f.read(8))
+        if d <= 0 or n < 0 or nfl != n * d:
+            raise RuntimeError("corrupt index file")
+        index = IndexFlat(d, metric, device)
+        if n:
+            index.reserve(n)
+        for r0 in range(0, n, chunk_rows):
+            m = min(chunk_rows, n - r0)
+            buf = f.read(m * d * 4)
+            if len(buf) != m * d * 4:
+                raise RuntimeError("truncated index file")
+            index.add(np.frombuffer(buf, dtype=np.float32).reshape(m, d))
+    return index

@@ -1,0 +1,159 @@
+/*
+ * css_hip.h -- C ABI of libcss_hip.so, the MI355X (gfx950) implementation of the
+ * embed-and-search hot path of pauloportella/claude-semantic-search.
+ *
+ * The reference is pure Python; its arithmetic is reached through two third
+ * party seams.  Each entry point below names the reference
+ * call site it replaces (paths relative to the reference checkout):
+ *
+ *   faiss.IndexFlatIP(d) / IndexFlatL2(d)    src/storage.py:252-258  -> css_index_create
+ *   faiss_index.add(x)                       src/storage.py:359      -> css_index_add
+ *   x / (norm + 1e-8) row-normalise          src/storage.py:347-350  -> css_index_add(normalize=1)
+ *   faiss_index.ntotal                       src/storage.py:358,421  -> css_index_ntotal
+ *   q / (norm + 1e-8), reshape(1,-1)         src/storage.py:424-429  -> css_index_search(normalize_q=1)
+ *   faiss_index.search(q, k) -> (D, I)       src/storage.py:436      -> css_index_search
+ *   faiss.write_index / read_index payload   src/storage.py:306,879  -> css_index_export / css_index_add
+ *   faiss.index_cpu_to_gpu / get_num_gpus    src/storage.py:283, src/gpu_utils.py:117-118
+ *                                                                    -> css_device_count / css_device_info
+ *   SentenceTransformer(name).encode(...)    src/embeddings.py:184-188, :216-222
+ *                                                                    -> css_encoder_forward
+ *   model.get_sentence_embedding_dimension() src/embeddings.py:117   -> css_encoder_cfg.hidden
+ *
+ * Conventions: extern "C", opaque handles, plain pointers and sizes.  Every
+ * function returns 0 on success or a negative css_status; the message for the
+ * calling thread is available from css_last_error().  Host pointers are caller
+ * owned and are consumed before return.  "_dev" twins take device pointers and
+ * a hipStream_t (as void*) and enqueue asynchronously on that stream; they are
+ * what a PyTorch-ROCm host passes tensor.data_ptr() / current_stream to.
+ * There is NO CPU fallback in this library: with no HIP device every compute
+ * entry point fails with CSS_ERR_NO_DEVICE.
+ */
+#ifndef CSS_HIP_H
+#define CSS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum css_status {
+    CSS_OK = 0,
+    CSS_ERR_INVALID = -1,   /* bad argument */
+    CSS_ERR_NO_DEVICE = -2, /* no usable HIP device */
+    CSS_ERR_HIP = -3,       /* HIP runtime error (message has the hipError string) */
+    CSS_ERR_OOM = -4,       /* device allocation failed */
+    CSS_ERR_STATE = -5      /* object not in a state that allows the call */
+} css_status;
+
+enum { CSS_METRIC_IP = 0, CSS_METRIC_L2 = 1 };
+
+/* Largest k accepted by css_index_search (the reference asks for
+ * min(max_results=100, ntotal): src/storage.py:432, :69). */
+#define CSS_MAX_K 128
+
+typedef struct css_devinfo {
+    char name[128];
+    char gcn_arch[64];
+    int compute_units;
+    int wavefront_size;
+    int64_t hbm_total_bytes;
+    int64_t hbm_free_bytes;
+    int lds_bytes_per_cu;
+    int clock_mhz;
+} css_devinfo;
+
+typedef struct css_index css_index;
+typedef struct css_encoder css_encoder;
+
+const char* css_version(void);
+const char* css_last_error(void);
+
+int css_device_count(int* n);
+int css_device_info(int device, css_devinfo* out);
+
+/* ---- flat exact index (IndexFlatIP / IndexFlatL2 semantics) ---- */
+int css_index_create(int dim, int metric, int device, css_index** out);
+int css_index_free(css_index* ix);
+int css_index_reset(css_index* ix);                 /* ntotal := 0, keeps capacity */
+int css_index_reserve(css_index* ix, int64_t n);    /* capacity >= n rows, no copy later */
+int css_index_ntotal(const css_index* ix, int64_t* n);
+int css_index_dim(const css_index* ix, int* dim);
+int css_index_metric(const css_index* ix, int* metric);
+int css_index_device(const css_index* ix, int* device);
+/* Global id of local row 0 (shards of a row-partitioned index). */
+int css_index_set_id_base(css_index* ix, int64_t base);
+
+/* Append n rows (row-major [n, dim] fp32).  normalize != 0 applies the
+ * reference's x / (||x||_2 + 1e-8) per row on the device while copying in. */
+int css_index_add(css_index* ix, const float* x_host, int64_t n, int normalize);
+int css_index_add_dev(css_index* ix, const float* x_dev, int64_t n, int normalize, void* stream);
+/* Append n rows generated on the device from include/css_synth.h:
+ * row r, column c = css_synth_normal(seed, (first_row + r) * dim + c). */
+int css_index_add_synthetic(css_index* ix, int64_t n, uint64_t seed, int64_t first_row,
+                            int normalize, void* stream);
+/* Copy rows [row0, row0 + n) back to the host as [n, dim] fp32. */
+int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_host);
+
+/* Exact top-k.  IP: D descending inner products.  L2: D ascending squared
+ * distances.  Ties: lower id first.  Fewer than k rows: I = -1 and
+ * D = -FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= CSS_MAX_K.
+ * normalize_q != 0 applies q / (||q||_2 + 1e-8) first (src/storage.py:426). */
+int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
+                     float* D_host, int64_t* I_host);
+int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,
+                         float* D_dev, int64_t* I_dev, void* stream);
+
+/* Merge `nparts` per-shard results ([nparts, nq, k] each) into the global
+ * top-k by (score, id); used after the RCCL all-gather of per-shard top-k. */
+int css_merge_topk_dev(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts,
+                       int64_t nq, int k, int metric, float* D_out_dev, int64_t* I_out_dev,
+                       int device, void* stream);
+
+/* ---- MPNet sentence encoder (all-mpnet-base-v2 architecture) ---- */
+typedef struct css_encoder_cfg {
+    int num_layers;       /* 12 */
+    int hidden;           /* 768 */
+    int heads;            /* 12 (head_dim = hidden / heads must be 64) */
+    int ffn;              /* 3072 */
+    int vocab;            /* 30527 */
+    int max_pos;          /* 514 */
+    int rel_buckets;      /* 32 */
+    int pad_id;           /* 1 */
+    int max_seq_len;      /* 384 (kernel limit 512) */
+    float ln_eps;         /* 1e-5 */
+    int compute;          /* 0 = bf16 MFMA (product), 1 = fp32 verification mode */
+} css_encoder_cfg;
+
+typedef struct css_tensor {
+    const char* name;     /* HF key, e.g. "encoder.layer.0.attention.attn.q.weight" */
+    const float* data;    /* host fp32, row-major */
+    int64_t numel;
+} css_tensor;
+
+int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out);
+int css_encoder_free(css_encoder* enc);
+int css_encoder_load_weights(css_encoder* enc, const css_tensor* tensors, int n);
+/* Seeded synthetic weights generated on the device ("synthetic weights"). */
+int css_encoder_init_synthetic(css_encoder* enc, uint64_t seed);
+/* Copy one named parameter (fp32 master copy) back to the host. */
+int css_encoder_export_weight(const css_encoder* enc, const char* name, float* out_host, int64_t numel);
+/* Packed var-len batch: input_ids[cu_seqlens[B]] tokens, sequence b occupies
+ * [cu_seqlens[b], cu_seqlens[b+1]); every length in [1, max_seq_len].
+ * out: [B, hidden] fp32 = masked mean-pool (+ L2 normalise when normalize != 0). */
+int css_encoder_forward(css_encoder* enc, const int32_t* input_ids_host, const int32_t* cu_seqlens_host,
+                        int B, int normalize, float* out_host);
+int css_encoder_forward_dev(css_encoder* enc, const int32_t* input_ids_dev, const int32_t* cu_seqlens_dev,
+                            int B, int total_tokens, int max_len, int normalize, float* out_dev, void* stream);
+
+/* ---- in-library kernel timing (HIP events on the launch stream) ---- */
+/* When enabled, each launch of a named dominant kernel is bracketed by HIP
+ * events on the stream it is launched on; css_prof_read drains and sums them. */
+int css_prof_enable(int on);
+int css_prof_reset(void);
+int css_prof_read(const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSS_HIP_H */

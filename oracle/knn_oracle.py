@@ -1,0 +1,191 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT CODE -- CPU oracle for the flat exact kNN.
+
+Python face of ``oracle/knn_oracle.c`` (ctypes) plus a numpy/BLAS restatement of
+faiss-cpu's batched path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; nothing under
+``claude_semantic_search_amd/`` does.
+
+What is restated (reference file:line, relative to the reference checkout):
+
+* ``HybridStorage.add_chunks`` numeric part, ``src/storage.py:343-359``:
+  ``x = np.array(.., float32)``; ``x / (||x|| + 1e-8)`` per row; ids are
+  ``ntotal .. ntotal+n-1``.
+* ``HybridStorage.search`` numeric part, ``src/storage.py:424-436``:
+  ``q / (||q|| + 1e-8)``; ``reshape(1,-1).astype(float32)``;
+  ``k' = min(max_results, ntotal)``; ``index.search(q, k')``.
+* ``faiss.IndexFlatIP`` / ``IndexFlatL2`` (third party, faiss-cpu>=1.11.0 per the
+  reference's ``pyproject.toml:9``; not installed, restated from its published
+  semantics -- SURVEY.md App. B): exact fp32 inner product, descending; exact
+  squared L2, ascending; int64 ids; ``-1`` padding.
+
+Pinned by the reference's own known-answer tests via
+``tests/golden/knn_reference_cases.json`` (see ``tests/test_oracle_knn.py``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+METRIC_IP = 0
+METRIC_L2 = 1
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = _HERE / "_build" / "libknn_oracle.so"
+    if not so.exists():
+        subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    lib = ctypes.CDLL(str(so))
+    f32p = ctypes.POINTER(ctypes.c_float)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    f64p = ctypes.POINTER(ctypes.c_double)
+    lib.knn_oracle_normalize_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int]
+    lib.knn_oracle_normalize_rows.restype = None
+    lib.knn_oracle_search.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int64,
+                                      ctypes.c_int, ctypes.c_int, f32p, i64p]
+    lib.knn_oracle_search.restype = None
+    lib.knn_oracle_rescore64.argtypes = [f32p, ctypes.c_int, f32p, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, i64p, f64p]
+    lib.knn_oracle_rescore64.restype = None
+    lib.knn_oracle_merge.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_int, f32p, i64p]
+    lib.knn_oracle_merge.restype = None
+    lib.knn_oracle_num_threads.restype = ctypes.c_int
+    lib.knn_oracle_set_threads.argtypes = [ctypes.c_int]
+    lib.knn_oracle_synth_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64]
+    lib.knn_oracle_synth_rows.restype = None
+    _LIB = lib
+    return lib
+
+
+def _f32(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _i64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+
+def num_threads() -> int:
+    return int(_lib().knn_oracle_num_threads())
+
+
+def set_threads(t: int) -> None:
+    _lib().knn_oracle_set_threads(int(t))
+
+
+def normalize_rows(x: np.ndarray) -> np.ndarray:
+    """``x / (||x||_2 + 1e-8)`` row-wise in fp32 (``src/storage.py:347-350``)."""
+    x = np.array(x, dtype=np.float32, order="C", copy=True)
+    if x.ndim == 1:
+        x = x.reshape(1, -1)
+    _lib().knn_oracle_normalize_rows(_f32(x), x.shape[0], x.shape[1])
+    return x
+
+
+def normalize_rows_numpy(x: np.ndarray) -> np.ndarray:
+    """Literal numpy form of the reference lines, for cross-checking the C one."""
+    x = np.array(x, dtype=np.float32)
+    norms = np.linalg.norm(x, axis=1, keepdims=True)
+    return (x / (norms + 1e-8)).astype(np.float32)
+
+
+def synth_rows(n: int, d: int, seed: int, first_row: int = 0) -> np.ndarray:
+    x = np.empty((n, d), dtype=np.float32)
+    _lib().knn_oracle_synth_rows(_f32(x), n, d, ctypes.c_uint64(seed), first_row)
+    return x
+
+
+class FlatIndexOracle:
+    """Duck-types the members of ``faiss.IndexFlatIP/L2`` the reference touches
+    (``.d``, ``.ntotal``, ``.add``, ``.search``, ``.reset``)."""
+
+    def __init__(self, d: int, metric: int = METRIC_IP):
+        self.d = int(d)
+        self.metric = int(metric)
+        self._xb = np.zeros((0, self.d), dtype=np.float32)
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._xb.shape[0])
+
+    def reset(self) -> None:
+        self._xb = np.zeros((0, self.d), dtype=np.float32)
+
+    def add(self, x: np.ndarray) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.d)
+        self._xb = np.ascontiguousarray(np.concatenate([self._xb, x], axis=0))
+
+    def search(self, q: np.ndarray, k: int):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib().knn_oracle_search(_f32(self._xb), self.ntotal, self.d, _f32(q), nq, int(k),
+                                 self.metric, _f32(D), _i64(I))
+        return D, I
+
+    def rescore64(self, q: np.ndarray, I: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.d)
+        I = np.ascontiguousarray(I, dtype=np.int64)
+        D64 = np.empty(I.shape, dtype=np.float64)
+        _lib().knn_oracle_rescore64(_f32(self._xb), self.d, _f32(q), q.shape[0], I.shape[1],
+                                    self.metric, _i64(I), D64.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return D64
+
+
+def merge_topk(D_parts: np.ndarray, I_parts: np.ndarray, metric: int = METRIC_IP):
+    """[nparts, nq, k] per-shard lists -> global top-k (SURVEY.md 8e exchange)."""
+    D_parts = np.ascontiguousarray(D_parts, dtype=np.float32)
+    I_parts = np.ascontiguousarray(I_parts, dtype=np.int64)
+    nparts, nq, k = D_parts.shape
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    _lib().knn_oracle_merge(_f32(D_parts), _i64(I_parts), nparts, nq, k, metric, _f32(D), _i64(I))
+    return D, I
+
+
+def search_blas(xb: np.ndarray, q: np.ndarray, k: int, metric: int = METRIC_IP, block: int = 65536):
+    """faiss-cpu's batched path (nq >= 20): blocked SGEMM + per-query heap merge,
+    restated with numpy (BLAS threads = all cores).  Used by bench.py as the
+    ``cpu_baseline`` of kind "port" for query batches."""
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    nq = q.shape[0]
+    n = xb.shape[0]
+    best_s = np.full((nq, 0), 0, dtype=np.float32)
+    best_i = np.zeros((nq, 0), dtype=np.int64)
+    qn = (q * q).sum(1)[:, None] if metric == METRIC_L2 else None
+    for r0 in range(0, n, block):
+        blk = xb[r0:r0 + block]
+        s = q @ blk.T
+        if metric == METRIC_L2:
+            s = qn + (blk * blk).sum(1)[None, :] - 2.0 * s
+            np.maximum(s, 0, out=s)
+            key = s
+        else:
+            key = -s
+        kk = min(k, blk.shape[0])
+        part = np.argpartition(key, kk - 1, axis=1)[:, :kk]
+        ps = np.take_along_axis(s, part, axis=1)
+        cand_s = np.concatenate([best_s, ps], axis=1)
+        cand_i = np.concatenate([best_i, part.astype(np.int64) + r0], axis=1)
+        ck = -cand_s if metric == METRIC_IP else cand_s
+        order = np.lexsort((cand_i, ck), axis=1)[:, :k]
+        best_s = np.take_along_axis(cand_s, order, axis=1)
+        best_i = np.take_along_axis(cand_i, order, axis=1)
+    if best_s.shape[1] < k:
+        pad = k - best_s.shape[1]
+        fill = -np.finfo(np.float32).max if metric == METRIC_IP else np.finfo(np.float32).max
+        best_s = np.concatenate([best_s, np.full((nq, pad), fill, np.float32)], axis=1)
+        best_i = np.concatenate([best_i, np.full((nq, pad), -1, np.int64)], axis=1)
+    return best_s.astype(np.float32), best_i

@@ -1,0 +1,208 @@
+"""GPU parity tests: hand-written HIP flat index (through the C ABI) vs the CPU oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from claude_semantic_search_amd import synth
+from tests_support import oracle_index, hip_index  # noqa: F401  (fixtures)
+from knn_checks import assert_topk_matches
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _run_case(n, d, nq, k, metric, normalize, seed=1):
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    x = synth.rows(n, d, seed)
+    q = synth.rows(nq, d, seed + 1000)
+    hip = IndexFlat(d, metric)
+    hip.add(x, normalize=normalize)
+    assert hip.ntotal == n
+    D, I = hip.search(q, k, normalize=normalize)
+    ref = ko.FlatIndexOracle(d, metric)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if normalize else (x, q)
+    ref.add(xr)
+    Dr, Ir = ref.search(qr, k)
+    D64 = ref.rescore64(qr, np.where(Ir < 0, 0, Ir))
+    assert_topk_matches(D, I, Dr, Ir, D64, f"n={n} d={d} nq={nq} k={k} metric={metric}")
+    hip.close()
+
+
+@pytest.mark.parametrize("case", json.loads((GOLD / "knn_reference_cases.json").read_text())["cases"],
+                         ids=lambda c: c["name"])
+def test_reference_known_answers_on_hip(case):
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(4)
+    ix.add(np.array(case["rows"], np.float32), normalize=True)
+    D, I = ix.search(np.array(case["query"], np.float32), min(100, ix.ntotal), normalize=True)
+    assert I[0].tolist() == case["expected_ids"]
+    assert np.allclose(D[0], case["expected_sims"], atol=1e-6)
+
+
+def test_env_case_on_hip():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    env = json.loads((GOLD / "knn_reference_cases.json").read_text())["env_case"]
+    v = np.random.default_rng(env["seed"]).random((env["n"], env["d"])).astype(np.float32)
+    ix = IndexFlatIP(env["d"])
+    assert ix.d == 128 and ix.ntotal == 0
+    ix.add(v)
+    assert ix.ntotal == 10
+    D, I = ix.search(v[0:1], 5)
+    assert D.shape == (1, 5) and I.shape == (1, 5) and I[0][0] == 0
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 257, 1000])
+def test_ragged_sizes_ip(n):
+    _run_case(n, 768, 3, min(10, 128), 0, True, seed=n)
+
+
+@pytest.mark.parametrize("d", [1, 4, 63, 64, 65, 128, 384, 768, 1024])
+def test_dims(d):
+    _run_case(777, d, 2, 10, 0, True, seed=d)
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 9, 16, 17, 33])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_query_counts(nq, metric):
+    _run_case(5000, 768, nq, 10, metric, metric == 0, seed=nq)
+
+
+@pytest.mark.parametrize("k", [1, 2, 10, 64, 100, 128])
+def test_k_values(k):
+    _run_case(20000, 768, 2, k, 0, True, seed=k)
+
+
+def test_k_larger_than_ntotal_pads():
+    _run_case(7, 768, 2, 100, 0, True)
+    _run_case(7, 768, 2, 100, 1, False)
+
+
+def test_l2_raw_rows():
+    _run_case(10000, 768, 4, 10, 1, False)
+
+
+def test_config2_100k_768_top10_single_query_path():
+    # BASELINE config 2 shape, the reference's real call shape nq=1 (src/storage.py:429) and a small batch
+    _run_case(100_000, 768, 1, 100, 0, True, seed=2)
+    _run_case(100_000, 768, 16, 10, 0, True, seed=3)
+
+
+def test_duplicates_and_ties_lower_id_first():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    base = synth.rows(50, 768, 5)
+    x = np.concatenate([base, base, base], axis=0)  # every row appears 3 times
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=True)
+    D, I = ix.search(base[7:8], 9, normalize=True)
+    assert I[0][:3].tolist() == [7, 57, 107]
+    assert D[0][0] == D[0][1] == D[0][2]
+    # constant vectors incl. an all-zero row (tests/test_incremental_indexing.py:88,129 of the reference)
+    c = np.ones((20, 768), np.float32)
+    c[5] = 0.0
+    ix2 = IndexFlatIP(768)
+    ix2.add(c, normalize=True)
+    D, I = ix2.search(np.ones((1, 768), np.float32), 20, normalize=True)
+    assert I[0][:19].tolist() == [i for i in range(20) if i != 5] and I[0][19] == 5
+    assert abs(D[0][0] - 1.0) < 1e-5 and D[0][19] == 0.0
+
+
+def test_committed_goldens_on_hip():
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    for name, metric, norm in (("knn_synth_ip.npz", 0, True), ("knn_synth_l2.npz", 1, False)):
+        g = np.load(GOLD / name)
+        ix = IndexFlat(int(g["d"]), metric)
+        ix.add_synthetic(int(g["n"]), int(g["seed_x"]), 0, normalize=norm)
+        q = synth.rows(int(g["nq"]), int(g["d"]), int(g["seed_q"]))
+        D, I = ix.search(q, int(g["k"]), normalize=norm)
+        assert_topk_matches(D, I, g["D"], g["I"].astype(np.int64), g["D64"], name)
+
+
+def test_device_synthetic_rows_equal_host_generator():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ix.add_synthetic(300, 99, first_row=12345, normalize=False)
+    assert np.array_equal(ix.reconstruct_n(0, 300), synth.rows(300, 768, 99, first_row=12345))
+    ix.add_synthetic(10, 98, first_row=0, normalize=False)
+    assert np.array_equal(ix.reconstruct_n(300, 10), synth.rows(10, 768, 98))
+
+
+def test_incremental_adds_and_growth():
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ref = ko.FlatIndexOracle(768)
+    q = ko.normalize_rows(synth.rows(3, 768, 500))
+    total = 0
+    for step, n in enumerate([1, 10, 100, 1500, 3000]):
+        x = synth.rows(n, 768, 600 + step)
+        ix.add(x, normalize=True)
+        ref.add(ko.normalize_rows(x))
+        total += n
+        assert ix.ntotal == total
+        D, I = ix.search(q, 10)
+        Dr, Ir = ref.search(q, min(10, total) if total >= 10 else 10)
+        D64 = ref.rescore64(q, np.where(Ir < 0, 0, Ir))
+        assert_topk_matches(D, I, Dr, Ir, D64, f"after {total} rows")
+    ix.reset()
+    assert ix.ntotal == 0
+
+
+def test_id_base_and_merge_parts_match_whole():
+    """Row-partitioned shards + merge == one index, on one GPU."""
+    import ctypes
+
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, d, nq, k, G = 8000, 768, 12, 10, 4
+    x = synth.rows(n, d, 21)
+    q = synth.rows(nq, d, 22)
+    whole = IndexFlatIP(d)
+    whole.add(x, normalize=True)
+    D, I = whole.search(q, k, normalize=True)
+    qd = torch.from_numpy(q).cuda()
+    Dp = torch.empty((G, nq, k), dtype=torch.float32, device="cuda")
+    Ip = torch.empty((G, nq, k), dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for g in range(G):
+        s = IndexFlatIP(d)
+        lo, hi = g * n // G, (g + 1) * n // G
+        s.add(x[lo:hi], normalize=True)
+        s.set_id_base(lo)
+        s.search_dev(qd.data_ptr(), nq, k, Dp[g].data_ptr(), Ip[g].data_ptr(), st, normalize=True)
+        shards.append(s)
+    Do = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    Io = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dp.data_ptr()), ctypes.c_void_p(Ip.data_ptr()), G, nq, k, 0,
+                                           ctypes.c_void_p(Do.data_ptr()), ctypes.c_void_p(Io.data_ptr()), 0,
+                                           ctypes.c_void_p(st)))
+    torch.cuda.synchronize()
+    assert np.array_equal(Io.cpu().numpy(), I)
+    assert np.array_equal(Do.cpu().numpy(), D)
+
+
+def test_invalid_arguments_raise():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(8)
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((2, 7), np.float32))
+    with pytest.raises(ValueError):
+        ix.search(np.zeros((1, 8), np.float32), 0)
+    with pytest.raises(ValueError):
+        ix.search(np.zeros((1, 8), np.float32), 129)
+    D, I = ix.search(np.zeros((1, 8), np.float32), 3)  # empty index: padded
+    assert I[0].tolist() == [-1, -1, -1]

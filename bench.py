@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the embed-and-search hot path on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched by
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``,
+one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[3], the configuration the north-star roofline
+target is quoted on): a 10M x 768 fp32 flat inner-product index resident in HBM,
+a batch of 1000 queries, exact top-10.  A "step" is one pass of the search path
+over the whole query batch.  With N GPUs the SAME 10M-row index is
+row-partitioned over the ranks (strong scaling); each step ends with one RCCL
+all-gather of the per-shard top-k and a merge.
+
+The JSON line also carries:
+  roofline      dominant kernel of the timed region, measured with HIP events on
+                the launch stream inside this run (css_prof_*).
+  cpu_baseline  the CPU oracle (kind "port") timed on this box's host cores on a
+                bounded sample of the same workload, rank 0 / N=1 only.
+  extra         single-query (the reference's real call shape) sweep latency and
+                its HBM roofline fraction; encoder throughput when available.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3    # dense fp32-input MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total index rows (all GPUs)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work")
+    return ap.parse_args()
+
+
+def cpu_baseline_knn(args, log):
+    """Oracle (numpy/BLAS port of faiss-cpu's batched path) on a bounded row sample."""
+    import numpy as np
+    from oracle import knn_oracle as ko
+
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    q = ko.normalize_rows(ko.synth_rows(args.nq, args.dim, 5))
+    probe_rows = 50_000
+    x = ko.normalize_rows(ko.synth_rows(probe_rows, args.dim, 4))
+    t0 = time.perf_counter()
+    ko.search_blas(x, q, args.k)
+    t_probe = time.perf_counter() - t0
+    rows = int(min(2_000_000, max(probe_rows, probe_rows * args.cpu_seconds / max(t_probe, 1e-3))))
+    rows = min(rows, args.rows)
+    x = ko.normalize_rows(ko.synth_rows(rows, args.dim, 4))
+    t0 = time.perf_counter()
+    ko.search_blas(x, q, args.k)
+    t = time.perf_counter() - t0
+    full = t * (args.rows / rows)
+    log(f"cpu baseline: {rows} rows x {args.nq} queries in {t:.2f}s (threads={blas_threads})")
+    return {
+        "value": args.nq / full,
+        "unit": "queries/s",
+        "cores": int(blas_threads),
+        "kind": "port",
+        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, numpy SGEMM + top-{args.k} "
+                  f"(oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- build this rank's shard in HBM (rows generated on the device) -------
+    lo = rank * args.rows // world
+    hi = (rank + 1) * args.rows // world
+    shard = hi - lo
+    stream = torch.cuda.current_stream().cuda_stream
+    index = IndexFlatIP(args.dim, device=local_rank)
+    index.reserve(shard)
+    t0 = time.perf_counter()
+    index.add_synthetic(shard, seed=4, first_row=lo, normalize=True, stream=stream)
+    index.set_id_base(lo)
+    torch.cuda.synchronize()
+    log(f"rank0 shard: {shard} rows x {args.dim} ({shard * args.dim * 4 / 1e9:.2f} GB) generated in "
+        f"{time.perf_counter() - t0:.2f}s")
+
+    q_host = synth.rows(args.nq, args.dim, 5)
+    q = torch.from_numpy(q_host).to(dev)
+    D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+    I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
+    if world > 1:
+        Dg = torch.empty((world, args.nq, args.k), dtype=torch.float32, device=dev)
+        Ig = torch.empty((world, args.nq, args.k), dtype=torch.int64, device=dev)
+        Dm = torch.empty_like(D)
+        Im = torch.empty_like(I)
+
+    def step():
+        index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+        if world > 1:
+            dist.all_gather_into_tensor(Dg, D)
+            dist.all_gather_into_tensor(Ig, I)
+            nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dg.data_ptr()), ctypes.c_void_p(Ig.data_ptr()),
+                                                   world, args.nq, args.k, 0, ctypes.c_void_p(Dm.data_ptr()),
+                                                   ctypes.c_void_p(Im.data_ptr()), local_rank,
+                                                   ctypes.c_void_p(stream)))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    nat.prof_reset()
+    nat.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    nat.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = args.nq * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
+    kernels = {}
+    for name in ("knn_scan_mfma", "knn_scan_small", "knn_merge", "knn_merge_parts"):
+        ms, n = nat.prof_read(name)
+        if n:
+            kernels[name] = (ms, n)
+    dom = max(kernels, key=lambda k_: kernels[k_][0]) if kernels else None
+    roofline = None
+    if dom:
+        ms, n = kernels[dom]
+        avg_s = ms / n / 1e3
+        sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one sweep of this rank's shard
+        if dom == "knn_scan_mfma":
+            nq_launch = args.nq * args.steps / n     # queries served per launch
+            flops = 2.0 * shard * args.dim * nq_launch
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": flops / avg_s / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+                        "launches": n, "avg_ms": ms / n, "hbm_GBps": sweep_bytes / avg_s / 1e9}
+        else:
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": sweep_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": sweep_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "launches": n, "avg_ms": ms / n}
+    nat.prof_reset()
+
+    # ---- extra: the reference's real call shape (one query, k'=100) -------------
+    extra = {}
+    if not args.no_extra:
+        D1 = torch.empty((1, 100), dtype=torch.float32, device=dev)
+        I1 = torch.empty((1, 100), dtype=torch.int64, device=dev)
+        for kq, Dq, Iq in ((10, D[:1], I[:1]), (100, D1, I1)):
+            for _ in range(3):
+                index.search_dev(q.data_ptr(), 1, kq, Dq.data_ptr(), Iq.data_ptr(), stream, normalize=True)
+            fence()
+            nat.prof_reset()
+            nat.prof_enable(True)
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                index.search_dev(q.data_ptr(), 1, kq, Dq.data_ptr(), Iq.data_ptr(), stream, normalize=True)
+            fence()
+            dt = (time.perf_counter() - t0) / reps
+            nat.prof_enable(False)
+            ms, n = nat.prof_read("knn_scan_small")
+            gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
+            extra[f"nq1_k{kq}"] = {"latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
+                                   "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS if gbs else None}
+            nat.prof_reset()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_knn(args, log)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            "metric": "queries/sec@top-10 over 10Mx768 flat index (1k-query batch)",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.rows}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
+                                   f"top-{args.k}, index row-partitioned over {world} GPU(s)",
+                       "rows_total": args.rows, "rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k,
+                       "parallelism": f"row-shard x{world} + all-gather(top-k)"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,8 @@
 //                   instruction, 256 B contiguous per row segment), VALU FMAs,
 //                   DPP row reduction, block-shared sorted top-k lists in LDS
 //                   with a grid-wide monotone threshold for pruning.  HBM bound
+//   k_scan_mfma     >16 queries: 128x128x32 tiles on v_mfma_f32_32x32x2_f32 (exact
+//                   fp32), LDS-staged and swizzled, fused top-k epilogue.    MFMA bound
 //   k_merge_final   per query: merge the per-block lists into the final top-k.
 #include "css_common.h"
 #include "css_knn_kernels.h"
@@ -266,6 +268,205 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------ scan (query batches, MFMA)
+// C[128 rows x 128 queries] = X[128 x 768] * Q^T on v_mfma_f32_32x32x2_f32 (exact
+// fp32 fmaf chains, 157 TFLOP/s dense peak).  Block = 4 waves; wave w owns query
+// columns [32w, 32w+32) x all 128 rows = 4 accumulator tiles (64 AGPR/VGPR).
+// Per K-step (BK = 32 floats): X tile and Q tile are staged global -> registers
+// -> LDS (double buffered, one barrier per step, loads for step t+1 in flight
+// during the MFMAs of step t).  LDS rows are 128 B; the 16-B chunk index is
+// XOR-swizzled with (row>>1)&7 so every ds_read_b128 lane group hits 16
+// different slots of the 256-B bank row.
+// After the last K-step of a row tile the epilogue compares the 64 scores a lane
+// holds (one query column per lane) with that query's current k-th best; only
+// when something passes is the tile spilled to an LDS scratch and inserted into
+// the wave-owned sorted lists.  Thresholds are also exchanged grid-wide (gthr).
+constexpr int MF_BM = 128, MF_BN = 128, MF_BK = 32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));  // plain clang vector: stays in VGPRs
+
+__device__ __forceinline__ int mf_swz(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int METRIC>
+__global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ xb, const float* __restrict__ xnorm2,
+                                                      const float* __restrict__ qpad, int nq_real, int64_t ntotal,
+                                                      int dpad, int k, int nstrips, int nqtiles,
+                                                      int64_t tiles_per_strip, int* __restrict__ gthr,
+                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                 // [2][128][32]
+    float* Bs = As + 2 * MF_BM * MF_BK;                         // [2][128][32]
+    float* scr = Bs + 2 * MF_BN * MF_BK;                        // [4 waves][32][33]
+    float* xn2s = scr + 4 * 32 * 33;                            // [128]
+    float* ls = xn2s + MF_BM;                                   // [128][k]
+    uint32_t* li = reinterpret_cast<uint32_t*>(ls + MF_BN * k);  // [128][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware decode: blocks l, l+8, l+16, ... (same XCD under round-robin dispatch)
+    // walk the query tiles of ONE strip, so the strip's rows are fetched once per XCD L2.
+    const int l = blockIdx.x;
+    const int strip = (l / (8 * nqtiles)) * 8 + (l & 7);
+    const int qtile = (l >> 3) % nqtiles;
+    const int64_t ntiles = (ntotal + MF_BM - 1) / MF_BM;
+    const int64_t t_begin = (int64_t)strip * tiles_per_strip;
+    const int64_t t_end = min(t_begin + tiles_per_strip, ntiles);
+    const int q_base = qtile * MF_BN;
+
+    for (int i = tid; i < MF_BN * k; i += 256) {
+        ls[i] = -INFINITY;
+        li[i] = kInvalidRow;
+    }
+    __syncthreads();
+    if (t_begin >= t_end) {
+        for (int i = tid; i < MF_BN * k; i += 256) {
+            const int j = i / k, p = i - j * k;
+            if (q_base + j < nq_real) {
+                const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
+                part_s[o] = -INFINITY;
+                part_i[o] = kInvalidRow;
+            }
+        }
+        return;
+    }
+
+    const int KT = dpad / MF_BK;
+    const int64_t n_it = (t_end - t_begin) * KT;
+    // staging map: thread -> (row = (tid>>3) + 32*i, 16-B chunk = tid&7), i = 0..3
+    const int srow = tid >> 3, schunk = tid & 7;
+    v4f ra[4], rb[4];
+
+// (macros, not lambdas: by-reference lambda captures left ra/rb in scratch memory)
+#define MF_GLOAD(RT, KT)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        int64_t row_ = (RT) * MF_BM + srow + 32 * i;                                                         \
+        row_ = row_ < ntotal ? row_ : ntotal - 1;                                                            \
+        ra[i] = *reinterpret_cast<const v4f*>(xb + row_ * (int64_t)dpad + (KT) * MF_BK + schunk * 4);     \
+        rb[i] = *reinterpret_cast<const v4f*>(qpad + (int64_t)(q_base + srow + 32 * i) * dpad +           \
+                                                 (KT) * MF_BK + schunk * 4);                                 \
+    }
+#define MF_SSTORE(BUF)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        *reinterpret_cast<v4f*>(As + (BUF) * MF_BM * MF_BK + mf_swz(srow + 32 * i, schunk)) = ra[i];      \
+        *reinterpret_cast<v4f*>(Bs + (BUF) * MF_BN * MF_BK + mf_swz(srow + 32 * i, schunk)) = rb[i];      \
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int jq = wave * 32 + fr;  // this lane's query column inside the tile
+    float thr_g = -INFINITY;
+
+    MF_GLOAD(t_begin, 0)
+    MF_SSTORE(0)
+    __syncthreads();
+    int cur = 0;
+    int64_t rt = t_begin;  // row tile / K-step of the tile being computed
+    int kt = 0;
+    for (int64_t it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it) {
+            const int64_t nrt = kt + 1 < KT ? rt : rt + 1;
+            const int nkt = kt + 1 < KT ? kt + 1 : 0;
+            MF_GLOAD(nrt, nkt)
+        }
+        const float* A = As + cur * MF_BM * MF_BK;
+        const float* B = Bs + cur * MF_BN * MF_BK;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // 8 k-values per chunk pair: lane half fh takes chunk 2c+fh
+            const v4f b = *reinterpret_cast<const v4f*>(B + mf_swz(jq, 2 * c + fh));
+            v4f a[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4f*>(A + mf_swz(32 * m + fr, 2 * c + fh));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b.w, acc[m], 0, 0, 0);
+            }
+        }
+        if (kt == KT - 1) {
+            // ---------------- epilogue of row tile rt ----------------
+            const int64_t row0 = rt * MF_BM;
+            if constexpr (METRIC == CSS_METRIC_L2) {
+                // s = 2 x.q - ||x||^2  (||q||^2 is added in the final merge)
+                if (tid < MF_BM) xn2s[tid] = row0 + tid < ntotal ? xnorm2[row0 + tid] : 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[m][r] = 2.f * acc[m][r] - xn2s[32 * m + (r & 3) + 8 * (r >> 2) + 4 * fh];
+            }
+            thr_g = key2f(__hip_atomic_load(&gthr[q_base + jq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float thr_l = ls[jq * k + (k - 1)];
+            const float thr = fmaxf(thr_l, thr_g);
+            const bool full_tile = row0 + MF_BM <= ntotal;
+            bool anyp = false;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) anyp |= acc[m][r] >= thr;
+            anyp &= jq + q_base < nq_real;
+            if (__ballot(anyp) != 0ull) {
+                float* S = scr + wave * (32 * 33);
+                bool changed = false;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fr] = acc[m][r];
+                    for (int rr = 0; rr < 32; ++rr) {
+                        const int64_t row = row0 + 32 * m + rr;
+                        const float sv = S[rr * 33 + fr];
+                        const bool pass = fh == 0 && (full_tile || row < ntotal) && q_base + jq < nq_real &&
+                                          sv >= thr_l && sv >= thr_g;
+                        unsigned long long mk = __ballot(pass);
+                        if (mk == 0ull) continue;
+                        while (mk) {
+                            const int src = __ffsll((long long)mk) - 1;
+                            mk &= mk - 1;
+                            const float cs = __shfl(sv, src);
+                            const int cj = wave * 32 + src;
+                            const bool ins = wave_insert<uint32_t>(ls + cj * k, li + cj * k, k, cs, (uint32_t)row, lane);
+                            changed |= ins && (fr == src);
+                        }
+                        thr_l = ls[jq * k + (k - 1)];
+                    }
+                }
+                if (changed && fh == 0 && thr_l > thr_g) atomicMax(&gthr[q_base + jq], f2key(thr_l));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
+        if (it + 1 < n_it) {
+            MF_SSTORE(cur ^ 1)
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (++kt == KT) {
+            kt = 0;
+            ++rt;
+        }
+    }
+#undef MF_GLOAD
+#undef MF_SSTORE
+    // part layout: [q][strip][k]
+    for (int i = tid; i < MF_BN * k; i += 256) {
+        const int j = i / k, p = i - j * k;
+        if (q_base + j < nq_real) {
+            const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
+            part_s[o] = ls[i];
+            part_i[o] = li[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ final merge
 // One block per query.  Scans the G*k per-block entries in rounds of CAP,
 // appends the ones that can still matter to an LDS buffer, wave 0 inserts them.
@@ -487,6 +688,44 @@ int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb
     return CSS_OK;
 }
 
+
+template <int METRIC>
+int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
+    const int nq_pad = (nq + MF_BN - 1) / MF_BN * MF_BN;
+    const int nqtiles = nq_pad / MF_BN;
+    const int64_t ntiles = (ix->ntotal + MF_BM - 1) / MF_BM;
+    // one block per CU (LDS bound); strips in multiples of 8 for the XCD-aware block decode
+    int nstrips = std::max(8, ix->num_cus / nqtiles / 8 * 8);
+    nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
+    const int64_t tps = (ntiles + nstrips - 1) / nstrips;
+    int rc;
+    if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
+    if (nq_pad > nq)
+        CSS_HIP_TRY(hipMemsetAsync(ix->qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
+    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad,
+                       host_f2key(-INFINITY));
+    CSS_LAUNCH_CHECK();
+    const size_t lds = (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 + (size_t)MF_BN * k * 8;
+    auto kern = k_scan_mfma<METRIC>;
+    CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        ProfScope ps("knn_scan_mfma", st);
+        hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qpad, nq,
+                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+        CSS_LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps("knn_merge", st);
+        hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, k,
+                           ix->gthr, ix->qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0);
+        CSS_LAUNCH_CHECK();
+    }
+    return CSS_OK;
+}
+
+// largest k the MFMA kernel's LDS lists hold next to its staging buffers
+constexpr int kMfmaMaxK = 64;
+
 // q_dev: raw [nq, dim] device queries.  Caller holds ws_mu and a shared lock on mu.
 int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
                       int64_t* I_dev, hipStream_t st) {
@@ -512,6 +751,10 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         CSS_HIP_TRY(hipMemcpyAsync(I_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, st));
         CSS_HIP_TRY(hipStreamSynchronize(st));
         return CSS_OK;
+    }
+    if (nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0) {
+        return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
+                                           : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
     }
     // queries per sweep: keep the block's LDS (queries + lists) <= 64 KiB so >= 2 blocks fit a CU
     int nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 4));

@@ -194,6 +194,37 @@ def test_id_base_and_merge_parts_match_whole():
     assert np.array_equal(Do.cpu().numpy(), D)
 
 
+# ---- query batches > 16 take the MFMA kernel (k <= 64) -------------------------
+@pytest.mark.parametrize("n,nq,k,metric", [
+    (1, 20, 5, 0), (127, 17, 10, 0), (128, 40, 10, 0), (129, 129, 64, 0), (130, 129, 64, 1),
+    (3000, 1000, 10, 0), (20000, 300, 10, 0), (20000, 300, 10, 1), (50000, 128, 1, 0), (40000, 257, 33, 0),
+])
+def test_mfma_batch_path(n, nq, k, metric):
+    _run_case(n, 768, nq, k, metric, metric == 0, seed=n + nq)
+
+
+@pytest.mark.parametrize("d", [4, 64, 96, 128, 1024])
+def test_mfma_batch_dims(d):
+    _run_case(4000, d, 64, 10, 0, True, seed=d)
+
+
+def test_config2_100k_768_1000_queries_top10():
+    # BASELINE.json configs[1]: 100k x 768 index, 1000 queries, top-10 vs the CPU oracle
+    _run_case(100_000, 768, 1000, 10, 0, True, seed=2)
+
+
+def test_mfma_duplicates_ties():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    base = synth.rows(300, 768, 5)
+    x = np.concatenate([base, base], axis=0)
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=True)
+    D, I = ix.search(base[:40], 4, normalize=True)
+    for r in range(40):
+        assert I[r][:2].tolist() == [r, r + 300] and D[r][0] == D[r][1]
+
+
 def test_invalid_arguments_raise():
     from claude_semantic_search_amd.flat_index import IndexFlatIP
 

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "css_encoder_export_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "css_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "css_encoder_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "css_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "css_mpnet_rel_bucket": (c_int, [c_int, c_int, c_int]),
     "css_prof_enable": (c_int, [c_int]),
     "css_prof_reset": (c_int, []),
     "css_prof_read": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),

@@ -1,12 +1,498 @@
-// css_encoder.hip -- MPNet encoder entry points (TEMPORARY: kernels land next commit).
+// css_encoder.hip -- MPNet sentence encoder (all-mpnet-base-v2 architecture) on gfx950.
+//
+// Replaces, behind include/css_hip.h, what the reference reaches through
+// SentenceTransformer.encode() (src/embeddings.py:184-188, :216-222): MPNet
+// encoder forward -> masked mean pooling -> L2 normalise.
+// Tokenisation stays on the host (claude_semantic_search_amd/tokenizer.py); the
+// boundary here is (packed input_ids, cu_seqlens).
+//
+// Pipeline per forward (one stream, no host syncs between kernels):
+//   k_embed_ln -> 12 x [ k_gemm<QKV> -> attention -> k_gemm<RESID> -> k_layernorm
+//                        -> k_gemm<GELU> -> k_gemm<RESID> -> k_layernorm ] -> k_pool_norm
+// Residual stream / LayerNorm / softmax / pooling are fp32; GEMM and attention
+// operands are bf16 (MFMA) in the product mode, fp32 in the verification mode.
 #include "css_common.h"
-extern "C" {
-#define CSS_TODO(name) css::set_error(name ": encoder not built yet"); return CSS_ERR_STATE
-int css_encoder_create(const css_encoder_cfg*, int, css_encoder**) { CSS_TODO("css_encoder_create"); }
-int css_encoder_free(css_encoder*) { return CSS_OK; }
-int css_encoder_load_weights(css_encoder*, const css_tensor*, int) { CSS_TODO("css_encoder_load_weights"); }
-int css_encoder_init_synthetic(css_encoder*, uint64_t) { CSS_TODO("css_encoder_init_synthetic"); }
-int css_encoder_export_weight(const css_encoder*, const char*, float*, int64_t) { CSS_TODO("css_encoder_export_weight"); }
-int css_encoder_forward(css_encoder*, const int32_t*, const int32_t*, int, int, float*) { CSS_TODO("css_encoder_forward"); }
-int css_encoder_forward_dev(css_encoder*, const int32_t*, const int32_t*, int, int, int, int, float*, void*) { CSS_TODO("css_encoder_forward_dev"); }
+#include "css_encoder_kernels.h"
+#include "../../include/css_synth.h"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace css;
+
+namespace {
+
+struct Param {
+    float* p = nullptr;
+    int64_t numel = 0;
+    uint32_t synth_id = 0;
+    float mean = 0.f, std = 0.02f;
+};
+
+struct LayerW {
+    float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+    bf16_t *wqkv_h, *wo_h, *w1_h, *w2_h;
+};
+
+__global__ void k_synth_fill(float* p, size_t n, uint64_t seed, float mean, float std) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = mean + std * css_synth_normal(seed, (uint64_t)i);
 }
+
+__global__ void k_build_bias_tab(const float* __restrict__ relw, const int* __restrict__ bucket, int heads, int maxL,
+                                 float* __restrict__ tab) {
+    const int n = 2 * maxL - 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * heads) return;
+    const int h = i / n, r = i - h * n;
+    tab[i] = relw[bucket[r] * heads + h];
+}
+
+__global__ void k_zero_row(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+}  // namespace
+
+// Bucket of a relative position (rel = key - query), transformers'
+// MPNetEncoder.relative_position_bucket (modeling_mpnet.py:312-348 in 5.15.0).
+// Evaluated in double: the only integer-valued cases are |rel| = 16, 32, 64 where
+// log(n/8)/log(16)*8 is exact in double as well (tests/test_encoder_host.py pins
+// all 1023 values against the transformers implementation).
+extern "C" int css_mpnet_rel_bucket(int rel, int num_buckets, int max_distance) {
+    int n = -rel;
+    const int half = num_buckets / 2;
+    int ret = n < 0 ? half : 0;
+    n = n < 0 ? -n : n;
+    const int max_exact = half / 2;
+    if (n < max_exact) return ret + n;
+    const double v = std::log((double)n / max_exact) / std::log((double)max_distance / max_exact) * (half - max_exact);
+    int large = max_exact + (int)v;
+    if (large > half - 1) large = half - 1;
+    return ret + large;
+}
+
+struct css_encoder {
+    css_encoder_cfg cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, Param> params;
+    float *wemb = nullptr, *pemb = nullptr, *embg = nullptr, *embb = nullptr, *relw = nullptr;
+    std::vector<LayerW> layers;
+    float* bias_tab = nullptr;  // [heads][2*maxL-1]
+    int* bucket_dev = nullptr;
+    bool weights_ready = false;
+    // activations (capacity in tokens / sequences)
+    int cap_tokens = 0, cap_seqs = 0;
+    float *x32 = nullptr, *pre32 = nullptr;          // [T, H] fp32
+    void *x16 = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;  // operand-typed
+    int32_t *ids_dev = nullptr, *cu_dev = nullptr;
+    float* out_dev = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+int alloc_param(css_encoder* e, const std::string& name, int64_t numel, uint32_t sid, float mean, float std,
+                float** out) {
+    float* p = nullptr;
+    hipError_t err = hipMalloc((void**)&p, (size_t)numel * sizeof(float));
+    if (err != hipSuccess) return css::hip_fail(err, "hipMalloc(weights)", __FILE__, __LINE__);
+    Param prm;
+    prm.p = p;
+    prm.numel = numel;
+    prm.synth_id = sid;
+    prm.mean = mean;
+    prm.std = std;
+    e->params[name] = prm;
+    *out = p;
+    return CSS_OK;
+}
+
+// HF key names.  q/k/v are views into the fused
+// [3H, H] weight / [3H] bias, in that order.
+int build_params(css_encoder* e) {
+    const css_encoder_cfg& c = e->cfg;
+    const int64_t H = c.hidden, F = c.ffn;
+    int rc;
+#define AP(name, n, sid, mean, std, ptr) \
+    if ((rc = alloc_param(e, name, n, sid, mean, std, ptr)) != CSS_OK) return rc
+    AP("embeddings.word_embeddings.weight", (int64_t)c.vocab * H, 0, 0.f, 0.02f, &e->wemb);
+    AP("embeddings.position_embeddings.weight", (int64_t)c.max_pos * H, 1, 0.f, 0.02f, &e->pemb);
+    AP("embeddings.LayerNorm.weight", H, 2, 1.f, 0.1f, &e->embg);
+    AP("embeddings.LayerNorm.bias", H, 3, 0.f, 0.05f, &e->embb);
+    AP("encoder.relative_attention_bias.weight", (int64_t)c.rel_buckets * c.heads, 4, 0.f, 0.1f, &e->relw);
+    e->layers.resize(c.num_layers);
+    for (int i = 0; i < c.num_layers; ++i) {
+        LayerW& L = e->layers[i];
+        const std::string pre = "encoder.layer." + std::to_string(i) + ".";
+        const uint32_t base = 16 + 16 * i;
+        AP(pre + "attention.attn.qkv.weight", 3 * H * H, base + 0, 0.f, 0.02f, &L.wqkv);
+        AP(pre + "attention.attn.qkv.bias", 3 * H, base + 1, 0.f, 0.05f, &L.bqkv);
+        AP(pre + "attention.attn.o.weight", H * H, base + 6, 0.f, 0.02f, &L.wo);
+        AP(pre + "attention.attn.o.bias", H, base + 7, 0.f, 0.05f, &L.bo);
+        AP(pre + "attention.LayerNorm.weight", H, base + 8, 1.f, 0.1f, &L.ln1g);
+        AP(pre + "attention.LayerNorm.bias", H, base + 9, 0.f, 0.05f, &L.ln1b);
+        AP(pre + "intermediate.dense.weight", F * H, base + 10, 0.f, 0.02f, &L.w1);
+        AP(pre + "intermediate.dense.bias", F, base + 11, 0.f, 0.05f, &L.b1);
+        AP(pre + "output.dense.weight", H * F, base + 12, 0.f, 0.02f, &L.w2);
+        AP(pre + "output.dense.bias", H, base + 13, 0.f, 0.05f, &L.b2);
+        AP(pre + "output.LayerNorm.weight", H, base + 14, 1.f, 0.1f, &L.ln2g);
+        AP(pre + "output.LayerNorm.bias", H, base + 15, 0.f, 0.05f, &L.ln2b);
+        // q/k/v views (weights: rows [0,H) [H,2H) [2H,3H) of the fused matrix)
+        const char* nm[3] = {"q", "k", "v"};
+        for (int j = 0; j < 3; ++j) {
+            Param w;
+            w.p = L.wqkv + (size_t)j * H * H;
+            w.numel = H * H;
+            w.synth_id = base + 2 * j;  // informational; synthetic init fills the fused tensors
+            e->params[pre + "attention.attn." + nm[j] + ".weight"] = w;
+            Param b;
+            b.p = L.bqkv + (size_t)j * H;
+            b.numel = H;
+            e->params[pre + "attention.attn." + nm[j] + ".bias"] = b;
+        }
+        CSS_HIP_TRY(hipMalloc((void**)&L.wqkv_h, (size_t)3 * H * H * 2));
+        CSS_HIP_TRY(hipMalloc((void**)&L.wo_h, (size_t)H * H * 2));
+        CSS_HIP_TRY(hipMalloc((void**)&L.w1_h, (size_t)F * H * 2));
+        CSS_HIP_TRY(hipMalloc((void**)&L.w2_h, (size_t)H * F * 2));
+    }
+#undef AP
+    const int maxL = c.max_seq_len;
+    CSS_HIP_TRY(hipMalloc((void**)&e->bias_tab, (size_t)c.heads * (2 * maxL - 1) * sizeof(float)));
+    CSS_HIP_TRY(hipMalloc((void**)&e->bucket_dev, (size_t)(2 * maxL - 1) * sizeof(int)));
+    std::vector<int> bucket(2 * maxL - 1);
+    for (int r = 0; r < 2 * maxL - 1; ++r) bucket[r] = css_mpnet_rel_bucket(r - (maxL - 1), c.rel_buckets, 128);
+    CSS_HIP_TRY(hipMemcpy(e->bucket_dev, bucket.data(), bucket.size() * sizeof(int), hipMemcpyHostToDevice));
+    return CSS_OK;
+}
+
+// After the fp32 masters change: bf16 operand copies + the per-head Toeplitz bias table.
+int finalize_weights(css_encoder* e) {
+    const css_encoder_cfg& c = e->cfg;
+    const size_t H = c.hidden, F = c.ffn;
+    hipStream_t st = e->stream;
+    for (auto& L : e->layers) {
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.wqkv, L.wqkv_h, 3 * H * H);
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.wo, L.wo_h, H * H);
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.w1, L.w1_h, F * H);
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.w2, L.w2_h, H * F);
+    }
+    const int n = c.heads * (2 * c.max_seq_len - 1);
+    hipLaunchKernelGGL(k_build_bias_tab, dim3((n + 255) / 256), dim3(256), 0, st, e->relw, e->bucket_dev, c.heads,
+                       c.max_seq_len, e->bias_tab);
+    CSS_LAUNCH_CHECK();
+    CSS_HIP_TRY(hipStreamSynchronize(st));
+    e->weights_ready = true;
+    return CSS_OK;
+}
+
+int ensure_acts(css_encoder* e, int T, int B) {
+    const css_encoder_cfg& c = e->cfg;
+    const size_t H = c.hidden, F = c.ffn;
+    const size_t es = c.compute == 0 ? 2 : 4;
+    if (T > e->cap_tokens) {
+        void* ptrs[] = {e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev};
+        for (void* p : ptrs)
+            if (p) CSS_HIP_TRY(hipFree(p));
+        e->cap_tokens = 0;
+        const size_t cap = (size_t)T + 128;
+        CSS_HIP_TRY(hipMalloc((void**)&e->x32, cap * H * 4));
+        CSS_HIP_TRY(hipMalloc((void**)&e->pre32, cap * H * 4));
+        CSS_HIP_TRY(hipMalloc((void**)&e->x16, cap * H * es));
+        CSS_HIP_TRY(hipMalloc((void**)&e->qkv, cap * 3 * H * es));
+        CSS_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * es));
+        CSS_HIP_TRY(hipMalloc((void**)&e->ffn, cap * F * es));
+        CSS_HIP_TRY(hipMalloc((void**)&e->ids_dev, cap * sizeof(int32_t)));
+        e->cap_tokens = (int)cap;
+    }
+    if (B > e->cap_seqs) {
+        if (e->cu_dev) CSS_HIP_TRY(hipFree(e->cu_dev));
+        if (e->out_dev) CSS_HIP_TRY(hipFree(e->out_dev));
+        e->cap_seqs = 0;
+        const size_t cap = (size_t)B + 64;
+        CSS_HIP_TRY(hipMalloc((void**)&e->cu_dev, (cap + 1) * sizeof(int32_t)));
+        CSS_HIP_TRY(hipMalloc((void**)&e->out_dev, cap * H * 4));
+        e->cap_seqs = (int)cap;
+    }
+    return CSS_OK;
+}
+
+template <typename TIn, int EPI>
+int launch_gemm(const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
+                int qscale_cols, hipStream_t st, const char* prof) {
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    auto kern = k_gemm<TIn, EPI>;
+    const size_t lds = 4 * 16384;
+    CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(prof, st);
+    hipLaunchKernelGGL(kern, dim3(ntn * ntm), dim3(256), lds, st, (const TIn*)A, (const TIn*)W, bias, resid, C, M, N,
+                       K, qscale_cols);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+template <typename TIn>
+int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, int T, int max_len, int normalize,
+                  float* out, hipStream_t st) {
+    const css_encoder_cfg& c = e->cfg;
+    const int H = c.hidden, F = c.ffn;
+    constexpr bool BF = sizeof(TIn) == 2;
+    int rc;
+    {
+        ProfScope ps("enc_embed_ln", st);
+        hipLaunchKernelGGL(k_embed_ln<768>, dim3((T + 3) / 4), dim3(256), 0, st, ids, cu, B, e->wemb, e->pemb,
+                           e->embg, e->embb, c.ln_eps, c.vocab, c.max_pos, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
+        CSS_LAUNCH_CHECK();
+    }
+    const int maxL = c.max_seq_len;
+    for (int li = 0; li < c.num_layers; ++li) {
+        const LayerW& L = e->layers[li];
+        const void* xin = BF ? e->x16 : (const void*)e->x32;
+        const void* wqkv = BF ? (const void*)L.wqkv_h : (const void*)L.wqkv;
+        if ((rc = launch_gemm<TIn, EPI_QKV>(xin, wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, st, "enc_gemm_qkv")) != CSS_OK)
+            return rc;
+        {
+            ProfScope ps("enc_attention", st);
+            if constexpr (BF) {
+                const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1) * 4;
+                hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B, (max_len + 127) / 128, c.heads), dim3(256), lds, st,
+                                   (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx);
+            } else {
+                hipLaunchKernelGGL(k_attention_f32, dim3(B, max_len, c.heads), dim3(64), 0, st, (const float*)e->qkv, cu,
+                                   e->bias_tab, maxL, H, (float*)e->ctx);
+            }
+            CSS_LAUNCH_CHECK();
+        }
+        const void* wo = BF ? (const void*)L.wo_h : (const void*)L.wo;
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->x32, e->pre32, T, H, H, 0, st, "enc_gemm_o")) != CSS_OK)
+            return rc;
+        {
+            ProfScope ps("enc_layernorm", st);
+            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, L.ln1g, L.ln1b,
+                               c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
+            CSS_LAUNCH_CHECK();
+        }
+        xin = BF ? e->x16 : (const void*)e->x32;
+        const void* w1 = BF ? (const void*)L.w1_h : (const void*)L.w1;
+        if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, nullptr, e->ffn, T, F, H, 0, st, "enc_gemm_ffn1")) != CSS_OK)
+            return rc;
+        const void* w2 = BF ? (const void*)L.w2_h : (const void*)L.w2;
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->x32, e->pre32, T, H, F, 0, st, "enc_gemm_ffn2")) != CSS_OK)
+            return rc;
+        {
+            ProfScope ps("enc_layernorm", st);
+            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, L.ln2g, L.ln2b,
+                               c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
+            CSS_LAUNCH_CHECK();
+        }
+    }
+    {
+        ProfScope ps("enc_pool", st);
+        hipLaunchKernelGGL(k_pool_norm<768>, dim3(B), dim3(256), 0, st, e->x32, cu, normalize, out);
+        CSS_LAUNCH_CHECK();
+    }
+    return CSS_OK;
+}
+
+int forward_any(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, int T, int max_len, int normalize,
+                float* out, hipStream_t st) {
+    if (!e->weights_ready) {
+        css::set_error("css_encoder_forward: weights not loaded (call css_encoder_load_weights or css_encoder_init_synthetic)");
+        return CSS_ERR_STATE;
+    }
+    CSS_REQUIRE(B >= 1 && T >= B, "css_encoder_forward: bad batch (B=%d, tokens=%d)", B, T);
+    CSS_REQUIRE(max_len >= 1 && max_len <= e->cfg.max_seq_len, "css_encoder_forward: max_len=%d outside [1, %d]", max_len,
+                e->cfg.max_seq_len);
+    return e->cfg.compute == 0 ? forward_typed<bf16_t>(e, ids, cu, B, T, max_len, normalize, out, st)
+                               : forward_typed<float>(e, ids, cu, B, T, max_len, normalize, out, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out) {
+    CSS_REQUIRE(cfg && out, "css_encoder_create: NULL argument");
+    CSS_REQUIRE(cfg->hidden == 768 && cfg->heads * 64 == cfg->hidden,
+                "css_encoder_create: kernels are built for hidden=768, head_dim=64 (got hidden=%d heads=%d)", cfg->hidden,
+                cfg->heads);
+    CSS_REQUIRE(cfg->ffn % 128 == 0 && cfg->ffn >= 128, "css_encoder_create: ffn must be a multiple of 128");
+    CSS_REQUIRE(cfg->num_layers >= 1 && cfg->num_layers <= 64, "css_encoder_create: num_layers out of range");
+    CSS_REQUIRE(cfg->max_seq_len >= 1 && cfg->max_seq_len <= 512, "css_encoder_create: max_seq_len outside [1, 512]");
+    CSS_REQUIRE(cfg->max_pos >= cfg->max_seq_len + 2, "css_encoder_create: max_pos must be >= max_seq_len + 2");
+    CSS_REQUIRE(cfg->vocab >= 4 && cfg->rel_buckets >= 4 && cfg->rel_buckets % 4 == 0, "css_encoder_create: bad vocab / rel_buckets");
+    CSS_REQUIRE(cfg->compute == 0 || cfg->compute == 1, "css_encoder_create: compute must be 0 (bf16) or 1 (fp32)");
+    int rc = css::check_device(device);
+    if (rc != CSS_OK) return rc;
+    DeviceGuard g(device);
+    css_encoder* e = new css_encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        delete e;
+        return css::hip_fail(err, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    rc = build_params(e);
+    if (rc != CSS_OK) {
+        css_encoder_free(e);
+        return rc;
+    }
+    *out = e;
+    return CSS_OK;
+}
+
+int css_encoder_free(css_encoder* e) {
+    if (!e) return CSS_OK;
+    DeviceGuard g(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->params) {
+        // q/k/v views alias the fused tensors: free only owning entries
+        const std::string& n = kv.first;
+        const bool view = n.find(".attn.q.") != std::string::npos || n.find(".attn.k.") != std::string::npos ||
+                          n.find(".attn.v.") != std::string::npos;
+        if (!view && kv.second.p) (void)hipFree(kv.second.p);
+    }
+    for (auto& L : e->layers) {
+        if (L.wqkv_h) (void)hipFree(L.wqkv_h);
+        if (L.wo_h) (void)hipFree(L.wo_h);
+        if (L.w1_h) (void)hipFree(L.w1_h);
+        if (L.w2_h) (void)hipFree(L.w2_h);
+    }
+    void* ptrs[] = {e->bias_tab, e->bucket_dev, e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev,
+                    e->cu_dev, e->out_dev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return CSS_OK;
+}
+
+int css_encoder_load_weights(css_encoder* e, const css_tensor* tensors, int n) {
+    CSS_REQUIRE(e && tensors && n >= 0, "css_encoder_load_weights: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int loaded = 0;
+    for (int i = 0; i < n; ++i) {
+        CSS_REQUIRE(tensors[i].name && tensors[i].data, "css_encoder_load_weights: tensor %d has NULL name/data", i);
+        std::string name = tensors[i].name;
+        const std::string pfx = "0.auto_model.";  // sentence-transformers module prefix
+        if (name.compare(0, pfx.size(), pfx) == 0) name = name.substr(pfx.size());
+        if (name.compare(0, 6, "mpnet.") == 0) name = name.substr(6);
+        if (name.compare(0, 7, "pooler.") == 0 || name == "embeddings.position_ids") continue;  // unused
+        auto it = e->params.find(name);
+        CSS_REQUIRE(it != e->params.end(), "css_encoder_load_weights: unknown parameter '%s'", name.c_str());
+        CSS_REQUIRE(it->second.numel == tensors[i].numel, "css_encoder_load_weights: '%s' has %lld elements, expected %lld",
+                    name.c_str(), (long long)tensors[i].numel, (long long)it->second.numel);
+        CSS_HIP_TRY(hipMemcpy(it->second.p, tensors[i].data, (size_t)tensors[i].numel * 4, hipMemcpyHostToDevice));
+        ++loaded;
+    }
+    (void)loaded;
+    return finalize_weights(e);
+}
+
+int css_encoder_init_synthetic(css_encoder* e, uint64_t seed) {
+    CSS_REQUIRE(e, "css_encoder_init_synthetic: NULL encoder");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    for (auto& kv : e->params) {
+        const std::string& n = kv.first;
+        const bool view = n.find(".attn.q.") != std::string::npos || n.find(".attn.k.") != std::string::npos ||
+                          n.find(".attn.v.") != std::string::npos;
+        if (view) continue;
+        const Param& p = kv.second;
+        hipLaunchKernelGGL(k_synth_fill, dim3(1024), dim3(256), 0, e->stream, p.p, (size_t)p.numel,
+                           css_synth_tensor_seed(seed, p.synth_id), p.mean, p.std);
+    }
+    // padding_idx rows are zero at init (word_embeddings[pad], position_embeddings[pad])
+    const int H = e->cfg.hidden;
+    hipLaunchKernelGGL(k_zero_row, dim3((H + 255) / 256), dim3(256), 0, e->stream, e->wemb + (size_t)e->cfg.pad_id * H, H);
+    hipLaunchKernelGGL(k_zero_row, dim3((H + 255) / 256), dim3(256), 0, e->stream, e->pemb + (size_t)e->cfg.pad_id * H, H);
+    CSS_LAUNCH_CHECK();
+    return finalize_weights(e);
+}
+
+int css_encoder_export_weight(const css_encoder* ce, const char* name, float* out_host, int64_t numel) {
+    css_encoder* e = const_cast<css_encoder*>(ce);
+    CSS_REQUIRE(e && name && out_host, "css_encoder_export_weight: NULL argument");
+    auto it = e->params.find(name);
+    CSS_REQUIRE(it != e->params.end(), "css_encoder_export_weight: unknown parameter '%s'", name);
+    CSS_REQUIRE(it->second.numel == numel, "css_encoder_export_weight: '%s' has %lld elements, not %lld", name,
+                (long long)it->second.numel, (long long)numel);
+    DeviceGuard g(e->device);
+    CSS_HIP_TRY(hipMemcpy(out_host, it->second.p, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return CSS_OK;
+}
+
+int css_encoder_debug_read(css_encoder* e, const char* what, float* out_host, int64_t numel) {
+    CSS_REQUIRE(e && what && out_host && numel > 0, "css_encoder_debug_read: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    const std::string w = what;
+    const bool bf = e->cfg.compute == 0;
+    const void* src = nullptr;
+    bool typed = true;  // operand-typed (bf16 in product mode) vs always fp32
+    if (w == "x32") { src = e->x32; typed = false; }
+    else if (w == "pre32") { src = e->pre32; typed = false; }
+    else if (w == "qkv") src = e->qkv;
+    else if (w == "ctx") src = e->ctx;
+    else if (w == "ffn") src = e->ffn;
+    CSS_REQUIRE(src != nullptr, "css_encoder_debug_read: unknown or unallocated buffer '%s'", what);
+    CSS_HIP_TRY(hipDeviceSynchronize());
+    if (typed && bf) {
+        std::vector<uint16_t> tmp((size_t)numel);
+        CSS_HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)numel * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < numel; ++i) {
+            const uint32_t u = (uint32_t)tmp[i] << 16;
+            memcpy(&out_host[i], &u, 4);
+        }
+    } else {
+        CSS_HIP_TRY(hipMemcpy(out_host, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    }
+    return CSS_OK;
+}
+
+int css_encoder_forward(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, int normalize, float* out) {
+    CSS_REQUIRE(e && ids && cu && out, "css_encoder_forward: NULL argument");
+    CSS_REQUIRE(B >= 1, "css_encoder_forward: B < 1");
+    CSS_REQUIRE(cu[0] == 0, "css_encoder_forward: cu_seqlens[0] must be 0");
+    int max_len = 0;
+    for (int b = 0; b < B; ++b) {
+        const int len = cu[b + 1] - cu[b];
+        CSS_REQUIRE(len >= 1 && len <= e->cfg.max_seq_len, "css_encoder_forward: sequence %d has length %d outside [1, %d]", b,
+                    len, e->cfg.max_seq_len);
+        max_len = len > max_len ? len : max_len;
+    }
+    const int T = cu[B];
+    for (int t = 0; t < T; ++t)
+        CSS_REQUIRE(ids[t] >= 0 && ids[t] < e->cfg.vocab && ids[t] != e->cfg.pad_id,
+                    "css_encoder_forward: token %d has id %d (outside the vocabulary or the pad id)", t, ids[t]);
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int rc = ensure_acts(e, T, B);
+    if (rc != CSS_OK) return rc;
+    CSS_HIP_TRY(hipMemcpyAsync(e->ids_dev, ids, (size_t)T * 4, hipMemcpyHostToDevice, e->stream));
+    CSS_HIP_TRY(hipMemcpyAsync(e->cu_dev, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    if ((rc = forward_any(e, e->ids_dev, e->cu_dev, B, T, max_len, normalize, e->out_dev, e->stream)) != CSS_OK) return rc;
+    CSS_HIP_TRY(hipMemcpyAsync(out, e->out_dev, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, e->stream));
+    CSS_HIP_TRY(hipStreamSynchronize(e->stream));
+    return CSS_OK;
+}
+
+int css_encoder_forward_dev(css_encoder* e, const int32_t* ids_dev, const int32_t* cu_dev, int B, int total_tokens,
+                            int max_len, int normalize, float* out_dev, void* stream) {
+    CSS_REQUIRE(e && ids_dev && cu_dev && out_dev, "css_encoder_forward_dev: NULL argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    int rc = ensure_acts(e, total_tokens, B);
+    if (rc != CSS_OK) return rc;
+    return forward_any(e, ids_dev, cu_dev, B, total_tokens, max_len, normalize, out_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

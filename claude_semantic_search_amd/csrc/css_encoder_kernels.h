@@ -1,0 +1,531 @@
+// css_encoder_kernels.h -- device kernels of the MPNet encoder (gfx950).
+//
+// Math follows SURVEY.md Appendix A (validated there against transformers'
+// modeling_mpnet.py): embeddings + LN, 12 post-LN layers with a shared T5-style
+// relative position bias, masked mean pooling, L2 normalise.
+//
+// Two compute modes share every kernel template:
+//   bf16 (product): GEMM / attention operands in bf16 on v_mfma_f32_32x32x16_bf16,
+//        fp32 accumulation; LayerNorm, softmax, residual stream, pooling in fp32.
+//   fp32 (verification): same tiling on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+// Activations are PACKED var-len: T = sum of sequence lengths rows, no padding.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "css_knn_kernels.h"
+
+namespace css {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;  // storage type of bf16 tensors
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// 128-byte LDS rows (64 bf16 or 32 f32) with the 16-B chunk index XOR-swizzled by
+// (row>>1)&7: every ds_read_b128 lane group then covers 16 distinct slots.
+__device__ __forceinline__ int swz_byte(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---------------------------------------------------------------- embeddings + LN
+// One wave per token.  H = hidden (multiple of 256 so that each lane owns H/64
+// contiguous... here: lane handles float4 columns lane*4 + 256*t).
+template <int H>
+__global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ ids, const int32_t* __restrict__ cu,
+                                                  int B, const float* __restrict__ wemb,
+                                                  const float* __restrict__ pemb, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float eps, int vocab, int max_pos,
+                                                  float* __restrict__ out32, bf16_t* __restrict__ out16, int T) {
+    constexpr int NV = H / 256;  // float4 per lane
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    // sequence of token t: binary search in cu_seqlens
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    int id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pos = (t - cu[lo]) + 2;  // packed (no pads): cumsum(mask)*mask + padding_idx(1)
+    pos = pos < max_pos ? pos : max_pos - 1;
+    const float4* w4 = reinterpret_cast<const float4*>(wemb + (size_t)id * H);
+    const float4* p4 = reinterpret_cast<const float4*>(pemb + (size_t)pos * H);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 a = w4[lane + 64 * i], b = p4[lane + 64 * i];
+        v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_allsum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float rstd = rsqrtf(wave_allsum(q) * (1.0f / H) + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + b.x;
+        o.y = (v[i].y - mean) * rstd * g.y + b.y;
+        o.z = (v[i].z - mean) * rstd * g.z + b.z;
+        o.w = (v[i].w - mean) * rstd * g.w + b.w;
+        reinterpret_cast<float4*>(out32 + (size_t)t * H)[lane + 64 * i] = o;
+        if (out16) {
+            ushort4 h;
+            h.x = f2bf(o.x); h.y = f2bf(o.y); h.z = f2bf(o.z); h.w = f2bf(o.w);
+            reinterpret_cast<ushort4*>(out16 + (size_t)t * H)[lane + 64 * i] = h;
+        }
+    }
+}
+
+// LayerNorm of fp32 rows (the GEMM epilogue already added bias + residual).
+template <int H>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps,
+                                                   float* __restrict__ out32, bf16_t* __restrict__ out16, int T) {
+    constexpr int NV = H / 256;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float4* x4 = reinterpret_cast<const float4*>(in + (size_t)t * H);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = x4[lane + 64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_allsum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float rstd = rsqrtf(wave_allsum(q) * (1.0f / H) + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + b.x;
+        o.y = (v[i].y - mean) * rstd * g.y + b.y;
+        o.z = (v[i].z - mean) * rstd * g.z + b.z;
+        o.w = (v[i].w - mean) * rstd * g.w + b.w;
+        reinterpret_cast<float4*>(out32 + (size_t)t * H)[lane + 64 * i] = o;
+        if (out16) {
+            ushort4 h;
+            h.x = f2bf(o.x); h.y = f2bf(o.y); h.z = f2bf(o.z); h.w = f2bf(o.w);
+            reinterpret_cast<ushort4*>(out16 + (size_t)t * H)[lane + 64 * i] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- GEMM
+// C[M,N] = A[M,K] * W[N,K]^T (+ epilogue).  Both operands are K-contiguous, so A
+// and W fragments are 16-B rows-of-K vectors.  Block 256 threads = 2x2 waves,
+// tile 128x128, K-step = 128 bytes of K (64 bf16 / 32 f32), register-staged
+// double buffer (loads of step t+1 in flight during the MFMAs of step t).
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+template <typename TIn>
+struct GemmTraits;
+template <>
+struct GemmTraits<bf16_t> {
+    static constexpr int BK = 64;
+};
+template <>
+struct GemmTraits<float> {
+    static constexpr int BK = 32;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// TIn: operand type (bf16_t or float).  Output: EPI_RESID -> fp32 [M,N] = acc + bias + resid;
+// EPI_QKV / EPI_GELU -> TIn [M,N]; EPI_QKV scales columns < qscale_cols by 0.125 (1/sqrt(64)).
+template <typename TIn, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
+                                                 const float* __restrict__ bias, const float* __restrict__ resid,
+                                                 void* __restrict__ Cout, int M, int N, int K, int qscale_cols) {
+    constexpr int BK = GemmTraits<TIn>::BK;
+    constexpr bool BF = sizeof(TIn) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;               // [2][128 rows][128 B]
+    char* Bs = smem + 2 * 16384;   // [2][128 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // XCD-aware tile order (bijective remap): each XCD walks a contiguous chunk of
+    // tiles, N fastest, so neighbouring blocks on one L2 share the A row panel.
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * 128, col0 = tn * 128;
+
+    const int srow = tid >> 3, schunk = tid & 7;
+    v4f ra[4], rb[4];
+    const int KT = K / BK;
+
+#define GM_GLOAD(KT_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+        int ar = row0 + srow + 32 * i;                                                                        \
+        ar = ar < M ? ar : M - 1;                                                                             \
+        int br = col0 + srow + 32 * i;                                                                        \
+        br = br < N ? br : N - 1;                                                                             \
+        ra[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(A + (size_t)ar * K + (KT_) * BK) + schunk * 16); \
+        rb[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(W + (size_t)br * K + (KT_) * BK) + schunk * 16); \
+    }
+#define GM_SSTORE(BUF)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+        *reinterpret_cast<v4f*>(As + (BUF) * 16384 + swz_byte(srow + 32 * i, schunk)) = ra[i];                \
+        *reinterpret_cast<v4f*>(Bs + (BUF) * 16384 + swz_byte(srow + 32 * i, schunk)) = rb[i];                \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    GM_GLOAD(0)
+    GM_SSTORE(0)
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) {
+            GM_GLOAD(kt + 1)
+        }
+        const char* Ab = As + cur * 16384;
+        const char* Bb = Bs + cur * 16384;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v4f a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + swz_byte(wr * 64 + 32 * m + fr, 2 * c + fh));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + swz_byte(wc * 64 + 32 * n + fr, 2 * c + fh));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if constexpr (BF) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[m]),
+                                                                            __builtin_bit_cast(v8bf, b[n]), acc[m][n], 0, 0, 0);
+                    } else {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+                    }
+                }
+        }
+        if (kt + 1 < KT) {
+            GM_SSTORE(cur ^ 1)
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef GM_GLOAD
+#undef GM_SSTORE
+
+    // epilogue: lane holds column (lane&31) of each 32x32 tile, rows (r&3)+8(r>>2)+4*fh
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = col0 + wc * 64 + 32 * n + fr;
+        if (col >= N) continue;
+        const float bv = bias[col];
+        const float sc = (EPI == EPI_QKV && col < qscale_cols) ? 0.125f : 1.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 64 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row >= M) continue;
+                float v = acc[m][n][r] + bv;
+                const size_t o = (size_t)row * N + col;
+                if constexpr (EPI == EPI_RESID) {
+                    reinterpret_cast<float*>(Cout)[o] = v + resid[o];
+                } else {
+                    if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
+                    if constexpr (EPI == EPI_QKV) v *= sc;
+                    if constexpr (BF) reinterpret_cast<bf16_t*>(Cout)[o] = f2bf(v);
+                    else reinterpret_cast<float*>(Cout)[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- attention (bf16, MFMA)
+// Block = (sequence, 128-query block, head), 4 waves x 32 queries.  Swapped
+// product S^T = K.Q^T keeps one query per lane (softmax in registers, one
+// cross-half exchange); O^T = V^T.P^T takes P^T straight from the accumulator
+// registers as the B operand (k order permuted: element j of lane half h is key
+// 16s + 8(j>>2) + 4h + (j&3)); the matching V^T fragments come from a row-major V
+// tile in LDS through ds_read_b64_tr_b16.  q is pre-scaled by 1/8 in the QKV
+// epilogue.  bias_tab[h][rel + (maxL-1)] holds W_rel[bucket(rel)][h], rel = key - query.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                        const float* __restrict__ bias_tab, int maxL, int hidden,
+                                                        bf16_t* __restrict__ ctx) {
+    static_assert(HD == 64, "head_dim 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                 // [2][64 keys][128 B]  (swizzled)
+    char* Vs = smem + 2 * 8192;      // [2][64 keys][128 B]  (row-major, d contiguous)
+    float* bt = reinterpret_cast<float*>(smem + 4 * 8192);  // [2*maxL-1]
+
+    const int b = blockIdx.x, qb = blockIdx.y, head = blockIdx.z;
+    const int tok0 = cu[b];
+    const int L = cu[b + 1] - tok0;
+    const int q0 = qb * 128;
+    if (q0 >= L) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ld = 3 * hidden;  // row stride of qkv in elements
+
+    const float* bsrc = bias_tab + (size_t)head * (2 * maxL - 1);
+    for (int i = tid; i < 2 * maxL - 1; i += 256) bt[i] = bsrc[i];
+
+    // this lane's query (clamped for loads; invalid queries are not stored)
+    const int qi = q0 + wave * 32 + fr;
+    const int qic = qi < L ? qi : L - 1;
+    // Q fragments as B operand: lane holds Q[query][16*ks + 8*fh + j]
+    v8bf qf[4];
+    {
+        const bf16_t* qp = qkv + (size_t)(tok0 + qic) * ld + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8bf*>(qp + 16 * ks + 8 * fh);
+    }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    const int nkt = (L + 63) / 64;
+    const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
+    v4f rk[2], rv[2];
+#define AT_GLOAD(KT_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+        int key = (KT_) * 64 + srow + 32 * i;                                                       \
+        key = key < L ? key : L - 1;                                                                \
+        const bf16_t* base = qkv + (size_t)(tok0 + key) * ld + head * HD + schunk * 8;              \
+        rk[i] = *reinterpret_cast<const v4f*>(base + hidden);                                       \
+        rv[i] = *reinterpret_cast<const v4f*>(base + 2 * hidden);                                   \
+    }
+#define AT_SSTORE(BUF)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+        *reinterpret_cast<v4f*>(Ks + (BUF) * 8192 + swz_byte(srow + 32 * i, schunk)) = rk[i];       \
+        *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + (srow + 32 * i) * 128 + schunk * 16) = rv[i];   \
+    }
+    AT_GLOAD(0)
+    AT_SSTORE(0)
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) {
+            AT_GLOAD(kt + 1)
+        }
+        const char* Kb = Ks + cur * 8192;
+        const char* Vb = Vs + cur * 8192;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = kt * 64 + sub * 32;
+            if (key0 >= L) break;  // block-uniform
+            // S^T[key][query] = K[key][:] . Q[query][:]
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), qf[ks], s, 0, 0, 0);
+            }
+            // bias + key mask, tile max
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float v = key < L ? s[r] + bt[key - qic + (maxL - 1)] : -INFINITY;
+                s[r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun, mloc);  // finite: key0 < L means at least one valid key
+            const float alpha = __expf(mrun - mnew);
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[r] - mnew);
+                s[r] = p;
+                lsum += p;
+            }
+            lrun = lrun * alpha + lsum;
+            mrun = mnew;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+            // O^T[d][query] += V^T[d][key] . P^T[key][query]
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                v8bf pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * st + j];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    // lane (d = 32*mt + fr, half fh): keys {16st+4fh+0..3} and {16st+8+4fh+0..3}
+                    // tr read: lane 4q+p of a 16-lane group addresses row key0'+q, columns d0+4p..4p+3
+                    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+                    const int dcol = 32 * mt + 16 * g16 + 4 * p4;
+                    const int kr0 = sub * 32 + 16 * st + 4 * fh + q4;
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (v4s __attribute__((address_space(3)))*)(Vb + kr0 * 128 + dcol * 2));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (v4s __attribute__((address_space(3)))*)(Vb + (kr0 + 8) * 128 + dcol * 2));
+                    // whole-vector shuffle + bitcast: per-element short -> __bf16 bitcasts of the
+                    // tr-read result were miscompiled by hipcc 7.2 into a splat of element 0
+                    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v8bf vf = __builtin_bit_cast(v8bf, both);
+                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[mt], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nkt) {
+            AT_SSTORE(cur ^ 1)
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef AT_GLOAD
+#undef AT_SSTORE
+    const float ltot = lrun + __shfl_xor(lrun, 32);
+    const float inv = 1.0f / ltot;
+    if (qi < L) {
+        bf16_t* op = ctx + (size_t)(tok0 + qi) * hidden + head * HD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ushort4 h;
+                h.x = f2bf(oacc[mt][4 * g + 0] * inv);
+                h.y = f2bf(oacc[mt][4 * g + 1] * inv);
+                h.z = f2bf(oacc[mt][4 * g + 2] * inv);
+                h.w = f2bf(oacc[mt][4 * g + 3] * inv);
+                *reinterpret_cast<ushort4*>(op + 32 * mt + 8 * g + 4 * fh) = h;
+            }
+    }
+}
+
+// fp32 verification attention: one wave per (sequence, head, query); plain loops.
+__global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                      const float* __restrict__ bias_tab, int maxL, int hidden,
+                                                      float* __restrict__ ctx) {
+    __shared__ float sc[512];
+    const int b = blockIdx.x, head = blockIdx.z, qi = blockIdx.y;
+    const int tok0 = cu[b];
+    const int L = cu[b + 1] - tok0;
+    if (qi >= L) return;
+    const int lane = threadIdx.x;
+    const int ld = 3 * hidden;
+    const float* q = qkv + (size_t)(tok0 + qi) * ld + head * 64;  // already scaled by 1/8
+    const float* bt = bias_tab + (size_t)head * (2 * maxL - 1);
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+        const float* kk = qkv + (size_t)(tok0 + j) * ld + hidden + head * 64;
+        float s = 0.f;
+        for (int d = 0; d < 64; ++d) s = fmaf(q[d], kk[d], s);
+        s += bt[j - qi + (maxL - 1)];
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float p = expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+    sum = wave_allsum(sum);
+    __syncthreads();
+    float o = 0.f;  // lane = output dim d
+    for (int j = 0; j < L; ++j) o = fmaf(sc[j], qkv[(size_t)(tok0 + j) * ld + 2 * hidden + head * 64 + lane], o);
+    ctx[(size_t)(tok0 + qi) * hidden + head * 64 + lane] = o / sum;
+}
+
+// ---------------------------------------------------------------- pooling
+// One block per sequence: e = sum_t y_t / max(len, 1e-9); optional e / max(||e||, 1e-12).
+template <int H>
+__global__ __launch_bounds__(256) void k_pool_norm(const float* __restrict__ y, const int32_t* __restrict__ cu,
+                                                   int normalize, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    constexpr int PER = (H + 255) / 256;
+    float acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+    for (int t = 0; t < L; ++t) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            if (c < H) acc[i] += y[(size_t)(t0 + t) * H + c];
+        }
+    }
+    const float denom = fmaxf((float)L, 1e-9f);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        acc[i] = acc[i] / denom;
+        if (tid + 256 * i < H) ss += acc[i] * acc[i];
+    }
+    ss = wave_allsum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        if (c < H) out[(size_t)b * H + c] = normalize ? acc[i] / nrm : acc[i];
+    }
+}
+
+// ---------------------------------------------------------------- weights
+__global__ void k_f32_to_bf16(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = f2bf(in[i]);
+}
+
+}  // namespace css

@@ -146,6 +146,16 @@ int css_encoder_forward(css_encoder* enc, const int32_t* input_ids_host, const i
 int css_encoder_forward_dev(css_encoder* enc, const int32_t* input_ids_dev, const int32_t* cu_seqlens_dev,
                             int B, int total_tokens, int max_len, int normalize, float* out_dev, void* stream);
 
+/* Test/diagnostic hook: copy an activation buffer of the LAST forward back to the
+ * host as fp32 ("x32" [T,H] final hidden states, "qkv" [T,3H], "ctx" [T,H],
+ * "ffn" [T,F], "pre32" [T,H]; with num_layers = 1 these are the layer-0 probes). */
+int css_encoder_debug_read(css_encoder* enc, const char* what, float* out_host, int64_t numel);
+
+/* Host-only helper (no device needed): bucket of a relative position
+ * rel = key - query, as transformers' MPNetEncoder.relative_position_bucket
+ * (the encoder builds its per-head Toeplitz bias table from it). */
+int css_mpnet_rel_bucket(int rel, int num_buckets, int max_distance);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---- */
 /* When enabled, each launch of a named dominant kernel is bracketed by HIP
  * events on the stream it is launched on; css_prof_read drains and sums them. */

@@ -1,0 +1,80 @@
+"""CPU: pins the encoder oracle (oracle/mpnet_oracle.py) against the in-container
+transformers.MPNetModel (the architecture all-mpnet-base-v2 uses) on seeded
+weights, and the host-side relative-position bucket helper of libcss_hip against
+transformers' own function."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpnet_oracle as mo
+
+transformers = pytest.importorskip("transformers")
+
+
+def _hf_model(cfg: mo.MpnetCfg, w):
+    from transformers import MPNetConfig, MPNetModel
+
+    hf = MPNetModel(MPNetConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers,
+                                num_attention_heads=cfg.heads, intermediate_size=cfg.ffn,
+                                max_position_embeddings=cfg.max_pos, layer_norm_eps=cfg.ln_eps,
+                                relative_attention_num_buckets=cfg.rel_buckets, hidden_act="gelu",
+                                hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+                    add_pooling_layer=False).eval()
+    missing, unexpected = hf.load_state_dict(w, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in m for m in missing), missing
+    return hf
+
+
+def test_oracle_matches_transformers_mpnet_padded_batch():
+    cfg = mo.MpnetCfg(num_layers=2)
+    w = mo.synth_weights(cfg, seed=7)
+    hf = _hf_model(cfg, w)
+    lengths = [40, 17, 2, 1]
+    batch = mo.synth_batch(cfg, lengths, seed=11)
+    Lmax = max(lengths)
+    ids = torch.full((len(batch), Lmax), cfg.pad_id, dtype=torch.long)
+    mask = torch.zeros((len(batch), Lmax), dtype=torch.long)
+    for b, s in enumerate(batch):
+        ids[b, :len(s)] = torch.tensor(s)
+        mask[b, :len(s)] = 1
+    with torch.no_grad():
+        hs = hf(input_ids=ids, attention_mask=mask).last_hidden_state
+    for b, s in enumerate(batch):
+        with torch.no_grad():
+            mine = mo.encode_tokens(w, cfg, s)
+        assert torch.allclose(mine, hs[b, :len(s)], atol=5e-6), float((mine - hs[b, :len(s)]).abs().max())
+    # sentence-transformers Pooling(mean) + Normalize on the HF output
+    m = mask[:, :, None].float()
+    pooled = (hs * m).sum(1) / m.sum(1).clamp(min=1e-9)
+    ref = torch.nn.functional.normalize(pooled, p=2, dim=1).numpy()
+    out = mo.encode(w, cfg, batch)
+    assert np.allclose(out, ref, atol=1e-6)
+    assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-6)
+
+
+def test_rel_bucket_table_spot_values_and_library_helper():
+    from transformers.models.mpnet import modeling_mpnet as mm
+    from claude_semantic_search_amd import _native as nat
+
+    rel = torch.arange(-511, 512)
+    hf = mm.MPNetEncoder.relative_position_bucket(rel.view(1, -1), num_buckets=32)[0]
+    assert torch.equal(mo.relative_position_bucket(rel, 32), hf)
+    # SURVEY.md 8(c) G6 spot values
+    assert hf[511 - 9:511 + 10].tolist() == [8, 8, 7, 6, 5, 4, 3, 2, 1, 0, 17, 18, 19, 20, 21, 22, 23, 24, 24]
+    assert int(hf[511 - 380]) == 15 and int(hf[511 + 380]) == 31
+    lib = nat.lib()
+    mine = [lib.css_mpnet_rel_bucket(int(r), 32, 128) for r in rel.tolist()]
+    assert mine == hf.tolist()
+
+
+def test_synth_weights_spec():
+    cfg = mo.MpnetCfg(num_layers=1)
+    w = mo.synth_weights(cfg, seed=3)
+    assert w["embeddings.word_embeddings.weight"].shape == (30527, 768)
+    assert float(w["embeddings.word_embeddings.weight"][cfg.pad_id].abs().max()) == 0.0
+    assert float(w["embeddings.position_embeddings.weight"][cfg.pad_id].abs().max()) == 0.0
+    assert abs(float(w["encoder.layer.0.intermediate.dense.weight"].std()) - 0.02) < 5e-4
+    assert abs(float(w["encoder.layer.0.attention.LayerNorm.weight"].mean()) - 1.0) < 2e-2
+    n = sum(v.numel() for v in w.values())
+    assert n == 30527 * 768 + 514 * 768 + 2 * 768 + 32 * 12 + (4 * (768 * 768 + 768) + 2 * 768 * 3072 + 3072 + 768 + 4 * 768)

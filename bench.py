@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work")
+    ap.add_argument("--enc-batch", type=int, default=256, help="encoder batch (sequences)")
+    ap.add_argument("--enc-len", type=int, default=384, help="encoder sequence length (tokens)")
+    ap.add_argument("--enc-steps", type=int, default=5)
+    ap.add_argument("--no-encoder", action="store_true")
     return ap.parse_args()
 
 
@@ -85,6 +89,95 @@ def cpu_baseline_knn(args, log):
         "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, numpy SGEMM + top-{args.k} "
                   f"(oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
     }
+
+
+def encoder_flops(lengths, layers=12):
+    """Algorithmic flops: per token per layer 14,155,776 (GEMMs) + 4*L*768 (attention)."""
+    return float(sum(layers * (L * 14155776 + 4 * L * L * 768) for L in lengths))
+
+
+def bench_encoder(args, dev, log):
+    """Batch-256 x 384-token encode (BASELINE.json configs[2]): synthetic ids + seeded weights."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+
+    B, L = args.enc_batch, args.enc_len
+    enc = MpnetEncoder(synthetic_seed=1, compute="bf16", device=dev.index or 0)
+    lengths = [L] * B
+    T = B * L
+    ids_h = synth.uint(7, np.arange(T, dtype=np.uint64), 4, enc.cfg["vocab"]).astype(np.int32)
+    ids_h[0::L] = 0
+    ids_h[L - 1::L] = 2
+    cu_h = (np.arange(B + 1, dtype=np.int64) * L).astype(np.int32)
+    ids = torch.from_numpy(ids_h).to(dev)
+    cu = torch.from_numpy(cu_h).to(dev)
+    out = torch.empty((B, 768), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        nat.check(nat.lib().css_encoder_forward_dev(enc._h, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(cu.data_ptr()),
+                                                    B, T, L, 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    nat.prof_reset()
+    nat.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.enc_steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.enc_steps
+    nat.prof_enable(False)
+    kern = {}
+    for name in ("enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn1", "enc_gemm_ffn2", "enc_attention", "enc_layernorm",
+                 "enc_embed_ln", "enc_pool"):
+        ms, n = nat.prof_read(name)
+        if n:
+            kern[name] = {"ms_per_batch": ms / args.enc_steps, "launches_per_batch": n // args.enc_steps}
+    nat.prof_reset()
+    fl = encoder_flops(lengths)
+    gemm_fl = {"enc_gemm_qkv": 2.0 * T * 768 * 2304 * 12, "enc_gemm_o": 2.0 * T * 768 * 768 * 12,
+               "enc_gemm_ffn1": 2.0 * T * 768 * 3072 * 12, "enc_gemm_ffn2": 2.0 * T * 768 * 3072 * 12,
+               "enc_attention": 12.0 * B * 4 * L * L * 768}
+    for k_, f in gemm_fl.items():
+        if k_ in kern:
+            kern[k_]["TFLOPs"] = f / (kern[k_]["ms_per_batch"] / 1e3) / 1e12
+    norms = out.norm(dim=1)
+    assert bool(torch.isfinite(out).all()) and float((norms - 1).abs().max()) < 1e-3
+    res = {
+        "chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "seq_len": L, "dtype": "bf16 MFMA, fp32 accumulate",
+        "algorithmic_TFLOP_per_batch": fl / 1e12,
+        "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": fl / dt / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None},
+        "kernels": kern,
+    }
+    log(f"encoder: {B}x{L} in {dt * 1e3:.2f} ms -> {B / dt:.0f} chunks/s, {fl / dt / 1e12:.0f} TFLOP/s")
+    if not args.no_cpu_baseline:
+        from oracle import mpnet_oracle as mo
+
+        cfg = mo.MpnetCfg()
+        w = mo.synth_weights(cfg, 1)
+        nb = 2
+        batch = [ids_h[i * L:(i + 1) * L].tolist() for i in range(nb)]
+        # one sequence at a time is small-matrix work: more threads than ~16 only thrash
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        ref = mo.encode(w, cfg, batch)
+        tc = time.perf_counter() - t0
+        cos = (out[:nb].cpu().numpy() * ref).sum(1)
+        res["cpu_baseline"] = {"value": nb / tc, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{nb} of the {B} sequences (L={L}) through oracle.mpnet_oracle (torch fp32)"}
+        res["parity_vs_oracle_min_cos"] = float(cos.min())
+        log(f"encoder cpu baseline: {nb} seqs in {tc:.2f}s; min cos vs oracle {cos.min():.6f}")
+    enc.close()
+    return res
 
 
 def main():
@@ -225,6 +318,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_knn(args, log)
+    if rank == 0 and world == 1 and not args.no_encoder:
+        index.close()  # free the 30 GB shard before the encoder leg
+        extra["encode"] = bench_encoder(args, dev, log)
 
     if world > 1:
         dist.barrier()

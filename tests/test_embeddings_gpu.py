@@ -1,0 +1,46 @@
+"""GPU: EmbeddingGenerator end to end on the HIP encoder (synthetic weights) and the
+embed -> add -> search drop-in sequence of the reference's orchestrator (src/cli.py:120-169, :232-251)."""
+import tempfile
+
+import numpy as np
+import pytest
+
+from claude_semantic_search_amd import Chunk, EmbeddingConfig, EmbeddingGenerator, HybridStorage, SearchConfig, StorageConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_embeddings_and_validation_cases():
+    g = EmbeddingGenerator(EmbeddingConfig(batch_size=8, use_gpu=True, show_progress=False, synthetic_weights_seed=1))
+    chunks = [Chunk("a", None), Chunk("b", ""), Chunk("c", "   \n"), Chunk("d", "valid text about python")]
+    out = g.generate_embeddings(chunks)           # tests/test_chunk_validation.py:113-163: len == 768 for all
+    assert out.shape == (4, 768) and g.embedding_dimension == 768
+    assert all(len(c.embedding) == 768 for c in chunks)
+    assert g.config.batch_size == 256             # src/gpu_utils.py:181-190 via auto_batch_size on a GPU
+    assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-4)
+    # reference sanitising (src/embeddings.py:197-213): None -> "", "" and blank -> "empty"
+    assert np.allclose(out[0], g.generate_single_embedding(""), atol=1e-6)
+    assert np.allclose(out[1], g.generate_single_embedding("empty"), atol=1e-6)
+    assert np.allclose(out[1], out[2], atol=1e-6)
+    info = g.get_model_info()
+    assert info["gpu_available"] and "gpu_info" in info and g.is_using_gpu
+
+
+def test_index_then_search_sequence():
+    texts = [f"conversation chunk number {i} about topic {i % 7} and python error handling" for i in range(300)]
+    with tempfile.TemporaryDirectory() as d:
+        emb = EmbeddingGenerator(EmbeddingConfig(batch_size=64, show_progress=False, synthetic_weights_seed=2))
+        st = HybridStorage(StorageConfig(data_dir=d, auto_save=True))
+        st.initialize()
+        emb.load_model()
+        chunks = [Chunk(f"chunk_{i:06d}", t, {"project_name": "p", "session_id": f"s{i % 3}"}) for i, t in enumerate(texts)]
+        emb.generate_embeddings(chunks)
+        st.add_chunks(chunks)
+        st.update_file_info("/nonexistent.jsonl", len(chunks))
+        q = emb.generate_single_embedding(texts[123])
+        res = st.search(q, SearchConfig(top_k=5), None)
+        assert res[0].chunk_id == "chunk_000123" and res[0].similarity > 0.999
+        assert all(res[i].similarity >= res[i + 1].similarity for i in range(4))
+        res = st.search(q, SearchConfig(top_k=5), {"session_id": "s0"})
+        assert res and all(r.metadata["session_id"] == "s0" for r in res)
+        st.close()

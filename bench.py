@@ -237,8 +237,8 @@ def main():
     def step():
         index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
         if world > 1:
-            dist.all_gather_into_tensor(Dg, D)
-            dist.all_gather_into_tensor(Ig, I)
+            dist.all_gather_into_tensor(Dg.view(world * args.nq, args.k), D)
+            dist.all_gather_into_tensor(Ig.view(world * args.nq, args.k), I)
             nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dg.data_ptr()), ctypes.c_void_p(Ig.data_ptr()),
                                                    world, args.nq, args.k, 0, ctypes.c_void_p(Dm.data_ptr()),
                                                    ctypes.c_void_p(Im.data_ptr()), local_rank,

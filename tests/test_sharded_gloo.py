@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the multi-GPU search skeleton (row partition ->
+local top-k -> one all-gather -> merge) equals one big index.  Device pieces are
+replaced by oracle-backed doubles defined here; the product wiring is covered on
+the GPU by tests/test_knn_gpu.py::test_id_base_and_merge_parts_match_whole."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FakeLocal:
+    def __init__(self, d, metric):
+        from oracle import knn_oracle as ko
+
+        self.ko, self.d, self.metric, self.base = ko, d, metric, 0
+        self.o = ko.FlatIndexOracle(d, metric)
+
+    ntotal = property(lambda self: self.o.ntotal)
+
+    def set_id_base(self, b):
+        self.base = int(b)
+
+    def reserve(self, n):
+        pass
+
+    def add(self, x, normalize=False):
+        self.o.add(self.ko.normalize_rows(x) if normalize else x)
+
+    def add_synthetic(self, n, seed, first_row=0, normalize=True, stream=0):
+        self.add(self.ko.synth_rows(n, self.d, seed, first_row), normalize)
+
+    def search(self, q, k, normalize=False):
+        D, I = self.o.search(self.ko.normalize_rows(q) if normalize else q, k)
+        return D, np.where(I >= 0, I + self.base, -1)
+
+
+def _merge(metric):
+    def f(Dg, Ig, k):
+        from oracle import knn_oracle as ko
+
+        D, I = ko.merge_topk(Dg.numpy(), Ig.numpy(), metric)
+        return torch.from_numpy(D), torch.from_numpy(I)
+    return f
+
+
+def _worker(rank, world, port, metric, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from claude_semantic_search_amd import synth
+        from claude_semantic_search_amd.sharded import ShardedFlatIndex, shard_bounds
+
+        d, n, nq, k = 64, 3001, 9, 10
+        sh = ShardedFlatIndex(d, metric, index_factory=lambda: _FakeLocal(d, metric), merge=_merge(metric))
+        assert (sh.rank, sh.world) == (rank, world)
+        sh.add_synthetic_global(n, seed=4, normalize=(metric == 0))
+        lo, hi = shard_bounds(n, world, rank)
+        assert sh.local.ntotal == hi - lo and sh.ntotal_global == n
+        q = synth.rows(nq, d, 5)
+        D, I = sh.search(q, k, normalize=(metric == 0))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), D=D, I=I)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_two_rank_sharded_search_equals_single_index(tmp_path, metric):
+    from oracle import knn_oracle as ko
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, metric, str(tmp_path)), nprocs=2, join=True)
+    d, n, nq, k = 64, 3001, 9, 10
+    x = ko.synth_rows(n, d, 4)
+    q = ko.synth_rows(nq, d, 5)
+    ref = ko.FlatIndexOracle(d, metric)
+    if metric == 0:
+        x, q = ko.normalize_rows(x), ko.normalize_rows(q)
+    ref.add(x)
+    Dr, Ir = ref.search(q, k)
+    for r in range(2):
+        got = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(got["I"], Ir), f"rank {r}"
+        assert np.array_equal(got["D"], Dr), f"rank {r}"
+
+
+def test_shard_bounds_cover_and_balance():
+    from claude_semantic_search_amd.sharded import shard_bounds
+
+    for n in (0, 1, 7, 8, 10_000_000, 80_000_001):
+        for w in (1, 2, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

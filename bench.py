@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--enc-len", type=int, default=384, help="encoder sequence length (tokens)")
     ap.add_argument("--enc-steps", type=int, default=5)
     ap.add_argument("--no-encoder", action="store_true")
+    ap.add_argument("--only-encoder", action="store_true", help="development aid: run just the encoder leg")
     return ap.parse_args()
 
 
@@ -206,6 +207,9 @@ def main():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.only_encoder:
+        print(json.dumps({"encode": bench_encoder(args, dev, log)}), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

@@ -16,6 +16,7 @@
 #include "../../include/css_synth.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -88,7 +89,7 @@ struct css_encoder {
     int* bucket_dev = nullptr;
     bool weights_ready = false;
     // activations (capacity in tokens / sequences)
-    int cap_tokens = 0, cap_seqs = 0;
+    int cap_tokens = 0, cap_seqs = 0, num_cus = 256;
     float *x32 = nullptr, *pre32 = nullptr;          // [T, H] fp32
     void *x16 = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;  // operand-typed
     int32_t *ids_dev = nullptr, *cu_dev = nullptr;
@@ -201,7 +202,8 @@ int ensure_acts(css_encoder* e, int T, int B) {
         for (void* p : ptrs)
             if (p) CSS_HIP_TRY(hipFree(p));
         e->cap_tokens = 0;
-        const size_t cap = (size_t)T + 128;
+        // GEMM tiles store whole 256-row tiles unconditionally: keep >= 256 slack rows
+        const size_t cap = ((size_t)T + 255) / 256 * 256 + 256;
         CSS_HIP_TRY(hipMalloc((void**)&e->x32, cap * H * 4));
         CSS_HIP_TRY(hipMalloc((void**)&e->pre32, cap * H * 4));
         CSS_HIP_TRY(hipMalloc((void**)&e->x16, cap * H * es));
@@ -223,18 +225,41 @@ int ensure_acts(css_encoder* e, int T, int B) {
     return CSS_OK;
 }
 
-template <typename TIn, int EPI>
-int launch_gemm(const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
-                int qscale_cols, hipStream_t st, const char* prof) {
-    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
-    auto kern = k_gemm<TIn, EPI>;
-    const size_t lds = 4 * 16384;
-    CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+extern int g_gemm_dbg;
+// Tile shapes: 2x2 waves x (2x2) MFMA tiles = 128x128, or 2x4 waves x (4x2) tiles = 256x256
+// (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN>
+int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
+                  int num_cus, hipStream_t st, const char* prof) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    CSS_REQUIRE(N % BN == 0 && K % 32 == 0 && K / 32 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN>;
+    const size_t lds = 4 * (size_t)(BM + BN) * 64;  // 4-deep ring of 64-B-row stages
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int grid = std::min(ntn * ntm, num_cus * blocks_per_cu);
+    grid = std::max(8, grid / 8 * 8);
     ProfScope ps(prof, st);
-    hipLaunchKernelGGL(kern, dim3(ntn * ntm), dim3(256), lds, st, (const TIn*)A, (const TIn*)W, bias, resid, C, M, N,
-                       K, qscale_cols);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, (const TIn*)A, (const TIn*)W, bias, C, M, N, K,
+                       qscale_cols, g_gemm_dbg);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
+}
+
+int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
+int g_gemm_big_tiles = 1;  // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
+
+template <typename TIn, int EPI>
+int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
+                int num_cus, hipStream_t st, const char* prof) {
+    if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0)
+        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
 }
 
 template <typename TIn>
@@ -255,7 +280,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         const LayerW& L = e->layers[li];
         const void* xin = BF ? e->x16 : (const void*)e->x32;
         const void* wqkv = BF ? (const void*)L.wqkv_h : (const void*)L.wqkv;
-        if ((rc = launch_gemm<TIn, EPI_QKV>(xin, wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, st, "enc_gemm_qkv")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_QKV>(xin, wqkv, L.bqkv, e->qkv, T, 3 * H, H, H, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_attention", st);
@@ -270,24 +295,24 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
             CSS_LAUNCH_CHECK();
         }
         const void* wo = BF ? (const void*)L.wo_h : (const void*)L.wo;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->x32, e->pre32, T, H, H, 0, st, "enc_gemm_o")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->pre32, T, H, H, 0, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_layernorm", st);
-            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, L.ln1g, L.ln1b,
+            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, e->x32, L.ln1g, L.ln1b,
                                c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
             CSS_LAUNCH_CHECK();
         }
         xin = BF ? e->x16 : (const void*)e->x32;
         const void* w1 = BF ? (const void*)L.w1_h : (const void*)L.w1;
-        if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, nullptr, e->ffn, T, F, H, 0, st, "enc_gemm_ffn1")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, e->ffn, T, F, H, 0, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         const void* w2 = BF ? (const void*)L.w2_h : (const void*)L.w2;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->x32, e->pre32, T, H, F, 0, st, "enc_gemm_ffn2")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->pre32, T, H, F, 0, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_layernorm", st);
-            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, L.ln2g, L.ln2b,
+            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, e->x32, L.ln2g, L.ln2b,
                                c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
             CSS_LAUNCH_CHECK();
         }
@@ -331,9 +356,15 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     int rc = css::check_device(device);
     if (rc != CSS_OK) return rc;
     DeviceGuard g(device);
+    if (const char* t = getenv("CSS_GEMM_TILE")) g_gemm_big_tiles = atoi(t) != 128;
+    if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;
+    {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, device) == hipSuccess) e->num_cus = p.multiProcessorCount;
+    }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         delete e;

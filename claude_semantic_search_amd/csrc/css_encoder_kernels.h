@@ -98,9 +98,11 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
     }
 }
 
-// LayerNorm of fp32 rows (the GEMM epilogue already added bias + residual).
+// LayerNorm of fp32 rows: LN(in + resid) (the GEMM epilogue added the bias; the residual
+// add lives here, where the access is perfectly coalesced, so the GEMM epilogue is store-only).
 template <int H>
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ resid,
+                                                   const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps,
                                                    float* __restrict__ out32, bf16_t* __restrict__ out16, int T) {
     constexpr int NV = H / 256;
@@ -108,11 +110,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
     const float4* x4 = reinterpret_cast<const float4*>(in + (size_t)t * H);
+    const float4* r4 = reinterpret_cast<const float4*>(resid + (size_t)t * H);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = x4[lane + 64 * i];
+        const float4 a = x4[lane + 64 * i], b = r4[lane + 64 * i];
+        v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_allsum(s) * (1.0f / H);
@@ -144,145 +148,268 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
 
 // ---------------------------------------------------------------- GEMM
 // C[M,N] = A[M,K] * W[N,K]^T (+ epilogue).  Both operands are K-contiguous, so A
-// and W fragments are 16-B rows-of-K vectors.  Block 256 threads = 2x2 waves,
-// tile 128x128, K-step = 128 bytes of K (64 bf16 / 32 f32), register-staged
-// double buffer (loads of step t+1 in flight during the MFMAs of step t).
+// and W fragments are 16-B rows-of-K vectors.  Block = WM x WN waves, each wave a
+// (32*TM) x (32*TN) output tile; K-step = 64 bytes of K (32 bf16 / 16 f32).
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction = 16 rows
+// x 64 B, lane i -> row i/4, physical 16-B chunk i%4) into a 4-deep ring of stages
+// with COUNTED vmcnt and a raw s_barrier: while stage s is multiplied, stages s+1,
+// s+2, s+3 are in flight (up to 96 KiB per CU for a 256x256 tile).  Measured on
+// MI355X (tools/probe_l2bw.hip): a CU's L2->LDS rate is latency x concurrency bound
+// (~1.3 us under load): 16/32/64 KiB in flight give 29/37/48 GB/s per CU, so the
+// 2-stage version of this kernel (one 64-KiB stage in flight) was load bound.
+// LDS rows are 64 B; physical chunk = logical ^ ((row>>2)&3) makes every
+// ds_read_b128 lane group hit 16 distinct 16-B slots; the swizzle is applied on the
+// per-lane SOURCE address of the DMA (its LDS destination is linear) and on reads.
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
 template <typename TIn>
 struct GemmTraits;
 template <>
 struct GemmTraits<bf16_t> {
-    static constexpr int BK = 64;
+    static constexpr int BK = 32;
 };
 template <>
 struct GemmTraits<float> {
-    static constexpr int BK = 32;
+    static constexpr int BK = 16;
 };
+
+__device__ __forceinline__ int swz64_byte(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// TIn: operand type (bf16_t or float).  Output: EPI_RESID -> fp32 [M,N] = acc + bias + resid;
-// EPI_QKV / EPI_GELU -> TIn [M,N]; EPI_QKV scales columns < qscale_cols by 0.125 (1/sqrt(64)).
-template <typename TIn, int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
-                                                 const float* __restrict__ bias, const float* __restrict__ resid,
-                                                 void* __restrict__ Cout, int M, int N, int K, int qscale_cols) {
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): two transcendentals + ~10 VALU
+// instead of erff's ~40; used where the result is rounded to bf16 anyway.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+// TIn: operand type (bf16_t or float).  Output: EPI_RESID -> fp32 [M,N] = acc + bias (the
+// residual is added by k_layernorm); EPI_QKV / EPI_GELU -> TIn [M,N]; EPI_QKV scales columns
+// < qscale_cols by 0.125 (1/sqrt(64)).
+//
+// PERSISTENT: one block per CU walks its share of the output tiles; the LDS-DMA ring runs
+// 3 stages ahead ACROSS tile boundaries (no per-tile pipeline fill), and a tile's epilogue
+// is store-only (bias comes from LDS), so its stores drain underneath the next tile's MFMAs.
+// vmcnt bookkeeping is exact: the only vector-memory operations in the steady state are
+// PPW LDS-DMA instructions per stage and E unconditional stores per tile (rows beyond M land
+// in the slack rows every activation buffer has).
+// dbg: timing experiments only (bit0 skip epilogue, bit1 skip MFMA, bit2 skip loads).
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
+                                                      const float* __restrict__ bias, void* __restrict__ Cout, int M,
+                                                      int N, int K, int qscale_cols, int dbg) {
     constexpr int BK = GemmTraits<TIn>::BK;
     constexpr bool BF = sizeof(TIn) == 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;               // [2][128 rows][128 B]
-    char* Bs = smem + 2 * 16384;   // [2][128 rows][128 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int NST = 4;                  // ring depth
+    constexpr int PIECES = (BM + BN) / 16;  // 1-KiB LDS-DMA pieces per stage
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;        // LDS-DMA instructions per wave per stage
+    constexpr int E = TM * TN * 4;          // store instructions per wave per tile
+    static_assert(2 * PPW + E <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST][A_BYTES | B_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
     const int fr = lane & 31, fh = lane >> 5;
 
-    // XCD-aware tile order (bijective remap): each XCD walks a contiguous chunk of
-    // tiles, N fastest, so neighbouring blocks on one L2 share the A row panel.
-    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    // XCD-aware persistent tile walk: XCD x (blocks with blockIdx % 8 == x under round-robin
+    // dispatch; speed only) owns a contiguous range of tiles in N-fastest order and its blocks
+    // advance through it side by side, so neighbouring blocks share A row panels in one L2.
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
     const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / ntn, tn = bid % ntn;
-    const int row0 = tm * 128, col0 = tn * 128;
-
-    const int srow = tid >> 3, schunk = tid & 7;
-    v4f ra[4], rb[4];
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
     const int KT = K / BK;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
 
-#define GM_GLOAD(KT_)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
-        int ar = row0 + srow + 32 * i;                                                                        \
-        ar = ar < M ? ar : M - 1;                                                                             \
-        int br = col0 + srow + 32 * i;                                                                        \
-        br = br < N ? br : N - 1;                                                                             \
-        ra[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(A + (size_t)ar * K + (KT_) * BK) + schunk * 16); \
-        rb[i] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(W + (size_t)br * K + (KT_) * BK) + schunk * 16); \
+    const int prow = lane >> 2, pchunk = lane & 3;
+    const char* src[PPW];  // issue-side per-lane source pointers (current issue tile)
+    int dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + NW * i;
+        const bool isA = piece < BM / 16;
+        dst[i] = (isA ? 0 : A_BYTES) + (isA ? piece : piece - BM / 16) * 1024;
     }
-#define GM_SSTORE(BUF)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
-        *reinterpret_cast<v4f*>(As + (BUF) * 16384 + swz_byte(srow + 32 * i, schunk)) = ra[i];                \
-        *reinterpret_cast<v4f*>(Bs + (BUF) * 16384 + swz_byte(srow + 32 * i, schunk)) = rb[i];                \
-    }
-
-    f32x16 acc[2][2];
+    auto set_src = [&](int tile_idx) {
+        const int tile = xfirst + jx + tile_idx * per_x;
+        const int r0 = (tile / ntn) * BM, c0 = (tile % ntn) * BN;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    GM_GLOAD(0)
-    GM_SSTORE(0)
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) {
-            GM_GLOAD(kt + 1)
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + NW * i;
+            const bool isA = piece < BM / 16;
+            const int trow = (isA ? piece : piece - BM / 16) * 16 + prow;
+            const int logical = pchunk ^ ((trow >> 2) & 3);
+            int grow = (isA ? r0 : c0) + trow;
+            const int lim = isA ? M : N;
+            grow = grow < lim ? grow : lim - 1;
+            src[i] = reinterpret_cast<const char*>((isA ? A : W) + (size_t)grow * K) + logical * 16;
         }
-        const char* Ab = As + cur * 16384;
-        const char* Bb = Bs + cur * 16384;
+    };
+#define GM_ISSUE(KT_, SLOT_)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * 64), \
+                                         (__attribute__((address_space(3))) void*)(smem + (SLOT_) * STAGE + dst[i]), 16, 0, 0); \
+    }
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            v4f a[2], b[2];
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + swz_byte(wr * 64 + 32 * m + fr, 2 * c + fh));
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + swz_byte(wc * 64 + 32 * n + fr, 2 * c + fh));
+            for (int r2 = 0; r2 < 16; ++r2) acc[m][n][r2] = 0.f;
+
+    // issue side runs NST-1 stages ahead of the compute side
+    int it_tile = 0, it_kt = 0, gi = 0;  // gi: global stage index of the next stage to issue
+    set_src(0);
+    for (int p = 0; p < NST - 1 && gi < total; ++p) {
+        if (!(dbg & 4)) {
+            GM_ISSUE(it_kt, gi % NST)
+        }
+        ++gi;
+        if (++it_kt == KT) {
+            it_kt = 0;
+            if (++it_tile < my_ntiles) set_src(it_tile);
+        }
+    }
+    int ct_tile = 0, kt = 0;
+    for (int g = 0; g < total; ++g) {
+        // stage g has landed once only the younger operations are outstanding
+        const int younger = min(NST - 2, total - 1 - g);
+        const bool stores_younger = ct_tile > 0 && kt < NST - 1;  // this tile's first stages were issued before the previous epilogue
+        if (dbg & 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + E) : "memory");  // (KT >= 3: two younger stages exist)
+        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // all pieces of stage g landed; the slot of stage g-1 is free
+        if (gi < total) {
+            if (!(dbg & 4)) {
+                GM_ISSUE(it_kt, gi % NST)
+            }
+            ++gi;
+            if (++it_kt == KT) {
+                it_kt = 0;
+                if (++it_tile < my_ntiles) set_src(it_tile);
+            }
+        }
+        const char* Ab = smem + (g % NST) * STAGE;
+        const char* Bb = Ab + A_BYTES;
+        if (!(dbg & 2))
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int c = 0; c < 2; ++c) {
+            v4f a[TM], b[TN];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
+            for (int m = 0; m < TM; ++m)
+                a[m] = *reinterpret_cast<const v4f*>(Ab + swz64_byte(wr * (TM * 32) + 32 * m + fr, 2 * c + fh));
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                b[n] = *reinterpret_cast<const v4f*>(Bb + swz64_byte(wc * (TN * 32) + 32 * n + fr, 2 * c + fh));
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    // transposed product: MFMA rows <- W rows (output columns), MFMA columns <-
+                    // tokens.  Each lane then owns ONE output row (token) and 4 consecutive
+                    // output columns per register group: 16-B (fp32) / 8-B (bf16) epilogue stores.
                     if constexpr (BF) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[m]),
-                                                                            __builtin_bit_cast(v8bf, b[n]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, b[n]),
+                                                                            __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
                     } else {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].x, a[m].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].y, a[m].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].z, a[m].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n].w, a[m].w, acc[m][n], 0, 0, 0);
                     }
                 }
         }
-        if (kt + 1 < KT) {
-            GM_SSTORE(cur ^ 1)
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-#undef GM_GLOAD
-#undef GM_SSTORE
-
-    // epilogue: lane holds column (lane&31) of each 32x32 tile, rows (r&3)+8(r>>2)+4*fh
+        if (++kt == KT) {
+            // ---- epilogue of tile ct_tile: bias (LDS) + activation + E unconditional stores.
+            // lane = token row (fr of the 32-row tile); register group g4 = the 4 consecutive
+            // output columns 8*g4 + 4*fh + {0..3} of each 32-column tile.
+            const int tile = xfirst + jx + ct_tile * per_x;
+            const int row0 = (tile / ntn) * BM, col0 = (tile % ntn) * BN;
+            // bias through the SCALAR path (wave-uniform address, s_load, lgkmcnt): an LDS copy
+            // of the bias made hipcc drain the LDS-DMA ring (vmcnt(0)) before reading it, and
+            // a vector load would sit on the counted vmcnt queue.
+            const int cuni = col0 + wc * (TN * 32);  // wave-uniform
+            const int cbase = cuni + 4 * fh;
+            if (!(dbg & 1)) {
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = col0 + wc * 64 + 32 * n + fr;
-        if (col >= N) continue;
-        const float bv = bias[col];
-        const float sc = (EPI == EPI_QKV && col < qscale_cols) ? 0.125f : 1.0f;
+                for (int m = 0; m < TM; ++m) {
+                    const size_t rbase = (size_t)(row0 + wr * (TM * 32) + 32 * m + fr) * N + cbase;  // may be a slack row
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+                    for (int n = 0; n < TN; ++n) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wr * 64 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row >= M) continue;
-                float v = acc[m][n][r] + bv;
-                const size_t o = (size_t)row * N + col;
-                if constexpr (EPI == EPI_RESID) {
-                    reinterpret_cast<float*>(Cout)[o] = v + resid[o];
-                } else {
-                    if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
-                    if constexpr (EPI == EPI_QKV) v *= sc;
-                    if constexpr (BF) reinterpret_cast<bf16_t*>(Cout)[o] = f2bf(v);
-                    else reinterpret_cast<float*>(Cout)[o] = v;
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int col = cbase + 32 * n + 8 * g4;
+                            const float* bp = bias + cuni + 32 * n + 8 * g4;  // uniform -> scalar loads
+                            float b8[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                float t = bp[j];
+                                asm volatile("" : "+s"(t));  // pin to an SGPR: keeps the load on the scalar path
+                                b8[j] = t;
+                            }
+                            float4 bv;
+                            bv.x = fh ? b8[4] : b8[0];
+                            bv.y = fh ? b8[5] : b8[1];
+                            bv.z = fh ? b8[6] : b8[2];
+                            bv.w = fh ? b8[7] : b8[3];
+                            float4 v;
+                            v.x = acc[m][n][4 * g4 + 0] + bv.x;
+                            v.y = acc[m][n][4 * g4 + 1] + bv.y;
+                            v.z = acc[m][n][4 * g4 + 2] + bv.z;
+                            v.w = acc[m][n][4 * g4 + 3] + bv.w;
+                            if constexpr (EPI == EPI_GELU) {
+                                if constexpr (BF) {
+                                    v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w);
+                                } else {
+                                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                                }
+                            }
+                            if constexpr (EPI == EPI_QKV) {
+                                const float sc = col < qscale_cols ? 0.125f : 1.0f;  // qscale_cols is a multiple of 4
+                                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                            }
+                            if constexpr (EPI == EPI_RESID || !BF) {
+                                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cout) + rbase + 32 * n + 8 * g4) = v;
+                            } else {
+                                ushort4 h;
+                                h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+                                *reinterpret_cast<ushort4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + 32 * n + 8 * g4) = h;
+                            }
+                        }
+                    }
                 }
             }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; ++r2) acc[m][n][r2] = 0.f;
+            kt = 0;
+            ++ct_tile;
         }
     }
+#undef GM_ISSUE
 }
 
 // ---------------------------------------------------------------- attention (bf16, MFMA)

@@ -468,9 +468,15 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ final merge
-// One block per query.  Scans the G*k per-block entries in rounds of CAP,
-// appends the ones that can still matter to an LDS buffer, wave 0 inserts them.
+// One block per query merges the G per-block lists (each sorted best-first) into
+// the final top-k, RANK-MAJOR: round r looks at rank r of every list that is still
+// alive.  A list whose rank-r entry cannot enter the current top-k is dead for
+// good (its later ranks are worse and the k-th best only improves), so after the
+// first round only a handful of lists stay alive.  Round 0 (all G heads) is a
+// block-wide bitonic sort in LDS; later rounds append the few survivors to an LDS
+// buffer and wave 0 inserts them.  G > 2048 is handled in chunks of 2048 lists.
 constexpr int kMergeCap = 2048;
+constexpr int kMergePerThread = kMergeCap / 256;
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ part_s,
                                                      const uint32_t* __restrict__ part_i, int G, int k,
@@ -484,30 +490,100 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
     __shared__ int cnt;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)q * G * k;
-    const int entries = G * k;
-    const float g = key2f(gthr[q]);
+    const float gfloor = key2f(gthr[q]);  // valid lower bound of the global k-th best
     for (int i = tid; i < k; i += 256) {
         fs[i] = -INFINITY;
         fi[i] = kInvalidRow;
     }
-    for (int start = 0; start < entries; start += kMergeCap) {
-        if (tid == 0) cnt = 0;
-        __syncthreads();
-        const float kth = fs[k - 1];
-        const uint32_t kid = fi[k - 1];
-        for (int e = start + tid; e < min(start + kMergeCap, entries); e += 256) {
-            const float s = part_s[base + e];
-            const uint32_t id = part_i[base + e];
-            if (id != kInvalidRow && s >= g && better<uint32_t>(s, id, kth, kid)) {
-                const int p = atomicAdd(&cnt, 1);
-                cs[p] = s;
-                ci[p] = id;
+    __syncthreads();
+    for (int c0 = 0; c0 < G; c0 += kMergeCap) {
+        const int nb = min(kMergeCap, G - c0);  // lists in this chunk
+        bool alive[kMergePerThread];
+#pragma unroll
+        for (int j = 0; j < kMergePerThread; ++j) alive[j] = tid + 256 * j < nb;
+        int r0 = 0;
+        if (c0 == 0) {
+            // round 0: bitonic sort (best first) of the nb heads, padded to a power of two
+            int n2 = 1;
+            while (n2 < nb) n2 <<= 1;
+            n2 = max(n2, 256);
+            for (int i = tid; i < n2; i += 256) {
+                float sv = -INFINITY;
+                uint32_t iv = kInvalidRow;
+                if (i < nb) {
+                    const size_t o = base + (size_t)(c0 + i) * k;
+                    const uint32_t id = part_i[o];
+                    const float v = part_s[o];
+                    if (id != kInvalidRow && v >= gfloor) {
+                        sv = v;
+                        iv = id;
+                    }
+                }
+                cs[i] = sv;
+                ci[i] = iv;
             }
+            __syncthreads();
+            for (int sz = 2; sz <= n2; sz <<= 1)
+                for (int st = sz >> 1; st > 0; st >>= 1) {
+                    for (int t = tid; t < n2 / 2; t += 256) {
+                        const int lo = 2 * t - (t & (st - 1));  // index with bit `st` clear
+                        const int hi = lo + st;
+                        const bool desc = (lo & sz) == 0;      // best-first in the first half of each block
+                        const float a = cs[lo], b2 = cs[hi];
+                        const uint32_t ia = ci[lo], ib = ci[hi];
+                        const bool a_first = better<uint32_t>(a, ia, b2, ib);
+                        if (a_first != desc) {
+                            cs[lo] = b2; ci[lo] = ib;
+                            cs[hi] = a;  ci[hi] = ia;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < k; i += 256) {
+                fs[i] = cs[i];   // n2 >= 256 >= k
+                fi[i] = ci[i];
+            }
+            __syncthreads();
+            // a head that did not make the top-k kills its list
+            const float kth = fs[k - 1];
+            const uint32_t kid = fi[k - 1];
+#pragma unroll
+            for (int j = 0; j < kMergePerThread; ++j) {
+                if (!alive[j]) continue;
+                const size_t o = base + (size_t)(c0 + tid + 256 * j) * k;
+                const uint32_t id = part_i[o];
+                const float v = part_s[o];
+                // alive iff the head is in the list, i.e. not worse than the k-th entry
+                alive[j] = id != kInvalidRow && v >= gfloor && !better<uint32_t>(kth, kid, v, id);
+            }
+            r0 = 1;
+            __syncthreads();
         }
-        __syncthreads();
-        if (wave == 0) {
+        for (int r = r0; r < k; ++r) {
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+            const float kth = fs[k - 1];
+            const uint32_t kid = fi[k - 1];
+#pragma unroll
+            for (int j = 0; j < kMergePerThread; ++j) {
+                if (!alive[j]) continue;
+                const size_t o = base + (size_t)(c0 + tid + 256 * j) * k + r;
+                const uint32_t id = part_i[o];
+                const float v = part_s[o];
+                if (id != kInvalidRow && v >= gfloor && better<uint32_t>(v, id, kth, kid)) {
+                    const int p = atomicAdd(&cnt, 1);
+                    cs[p] = v;
+                    ci[p] = id;
+                } else {
+                    alive[j] = false;
+                }
+            }
+            __syncthreads();
             const int n = cnt;
-            for (int c = 0; c < n; ++c) wave_insert<uint32_t>(fs, fi, k, cs[c], ci[c], lane);
+            if (n == 0) break;  // block-uniform
+            if (wave == 0)
+                for (int c = 0; c < n; ++c) wave_insert<uint32_t>(fs, fi, k, cs[c], ci[c], lane);
+            __syncthreads();
         }
         __syncthreads();
     }

@@ -26,6 +26,8 @@
 #include "../../include/css_synth.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <cfloat>
 #include <cmath>
 #include <mutex>
@@ -45,6 +47,7 @@ struct css_index {
     float* q_raw = nullptr;   size_t q_raw_cap = 0;     // floats
     float* qpad = nullptr;    size_t qpad_cap = 0;      // floats
     float* qnorm2 = nullptr;  size_t qnorm2_cap = 0;    // floats
+    unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
     float* out_d = nullptr;   int64_t* out_i = nullptr; size_t out_cap = 0;     // entries
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
 // the wave-owned sorted lists.  Thresholds are also exchanged grid-wide (gthr).
 constexpr int MF_BM = 128, MF_BN = 128, MF_BK = 32;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));  // plain clang vector: stays in VGPRs
 
 __device__ __forceinline__ int mf_swz(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -465,6 +469,270 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
             part_i[o] = li[i];
         }
     }
+}
+
+// Split-bf16 variant of k_scan_mfma: every fp32 operand is split on the fly into a bf16 pair
+// (h, l), x ~= h + l to 16 significant bits, and the four products (h+l).(h+l) run on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate, 4 MFMAs instead of 8x2): ~4x the
+// throughput at fp32-grade error (operand truncation 2^-17, random sign over 768 terms:
+// ~1e-7 on unit vectors, same order as fp32 accumulation order effects).  The index stays
+// fp32 in HBM; queries are pre-split once per search (k_split_queries).
+template <int METRIC>
+__global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restrict__ xb, const float* __restrict__ xnorm2,
+                                                      const unsigned short* __restrict__ qsplit, int nq_real, int64_t ntotal,
+                                                      int dpad, int k, int nstrips, int nqtiles,
+                                                      int64_t tiles_per_strip, int* __restrict__ gthr,
+                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                 // [2][128][32]
+    float* Bs = As + 2 * MF_BM * MF_BK;                         // [2][128][32]
+    float* xn2s = Bs + 2 * MF_BN * MF_BK;                       // [128]
+    int* eflag = reinterpret_cast<int*>(xn2s + MF_BM);          // [2] slow-path votes (alternating)
+    float* ls = xn2s + MF_BM + 4;                               // [128][k]
+    uint32_t* li = reinterpret_cast<uint32_t*>(ls + MF_BN * k);  // [128][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware decode: blocks l, l+8, l+16, ... (same XCD under round-robin dispatch)
+    // walk the query tiles of ONE strip, so the strip's rows are fetched once per XCD L2.
+    const int l = blockIdx.x;
+    const int strip = (l / (8 * nqtiles)) * 8 + (l & 7);
+    const int qtile = (l >> 3) % nqtiles;
+    const int64_t ntiles = (ntotal + MF_BM - 1) / MF_BM;
+    const int64_t t_begin = (int64_t)strip * tiles_per_strip;
+    const int64_t t_end = min(t_begin + tiles_per_strip, ntiles);
+    const int q_base = qtile * MF_BN;
+
+    for (int i = tid; i < MF_BN * k; i += 256) {
+        ls[i] = -INFINITY;
+        li[i] = kInvalidRow;
+    }
+    if (tid < 2) eflag[tid] = 0;
+    __syncthreads();
+    if (t_begin >= t_end) {
+        for (int i = tid; i < MF_BN * k; i += 256) {
+            const int j = i / k, p = i - j * k;
+            if (q_base + j < nq_real) {
+                const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
+                part_s[o] = -INFINITY;
+                part_i[o] = kInvalidRow;
+            }
+        }
+        return;
+    }
+
+    const int KT = dpad / MF_BK;
+    const int64_t n_it = (t_end - t_begin) * KT;
+    // staging map: thread -> (row = (tid>>3) + 32*i, 16-B chunk = tid&7), i = 0..3
+    const int srow = tid >> 3, schunk = tid & 7;
+    const int arow = tid >> 2, akg = tid & 3;
+    v4f ra0[4], rb0[4], ra1[4], rb1[4];  // two prefetch sets: loads run two K-steps ahead
+
+// (macros, not lambdas: by-reference lambda captures left ra/rb in scratch memory)
+// A: thread -> row (tid>>2) + 64*i, 8 consecutive k = (tid&3)*8 (two float4), converted here to
+// the bf16 pair (h, l) with x ~= h + l (16 significant bits); LDS row = [h k0..31 | l k0..31].
+// B: the pre-split queries are copied 16 B at a time (thread -> row (tid>>3) + 32*i, chunk tid&7).
+#define MF_GLOAD(RT, KT, RA, RB)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+        int64_t row_ = (RT) * MF_BM + arow + 64 * i;                                                         \
+        row_ = row_ < ntotal ? row_ : ntotal - 1;                                                            \
+        const float* p_ = xb + row_ * (int64_t)dpad + (KT) * MF_BK + akg * 8;                                \
+        RA[2 * i] = *reinterpret_cast<const v4f*>(p_);                                                       \
+        RA[2 * i + 1] = *reinterpret_cast<const v4f*>(p_ + 4);                                               \
+    }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        RB[i] = *reinterpret_cast<const v4f*>(qsplit + ((int64_t)(q_base + srow + 32 * i) * (dpad / MF_BK) + (KT)) * 64 + \
+                                              schunk * 8);                                                   \
+    }
+#define MF_SSTORE(BUF, RA, RB)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+        v8bf h_, l_;                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+            const float x_ = j < 4 ? RA[2 * i][j] : RA[2 * i + 1][j - 4];                                    \
+            const __bf16 hb_ = (__bf16)x_;                                                                   \
+            h_[j] = hb_;                                                                                     \
+            l_[j] = (__bf16)(x_ - (float)hb_);                                                               \
+        }                                                                                                    \
+        char* A_ = reinterpret_cast<char*>(As + (BUF) * MF_BM * MF_BK);                                      \
+        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + 64 * i, akg) * 4) = h_;                                  \
+        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + 64 * i, 4 + akg) * 4) = l_;                              \
+    }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        *reinterpret_cast<v4f*>(Bs + (BUF) * MF_BN * MF_BK + mf_swz(srow + 32 * i, schunk)) = RB[i];         \
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int jq = wave * 32 + fr;  // this lane's query column inside the tile
+    float thr_g = -INFINITY;
+
+    // software pipeline: global loads run TWO K-steps ahead in two register sets (one K-step of
+    // MFMAs is shorter than the L2/HBM latency), LDS is double buffered one step ahead.
+    int64_t rt = t_begin;  // row tile / K-step of the tile being computed
+    int kt = 0;
+    int64_t lrt = t_begin;  // (row tile, K-step) of the next global load to issue
+    int lkt = 0;
+#define MF_ADVANCE_LOAD()   \
+    if (++lkt == KT) {      \
+        lkt = 0;            \
+        ++lrt;              \
+    }
+    MF_GLOAD(lrt, lkt, ra0, rb0)
+    MF_ADVANCE_LOAD()
+    if (n_it > 1) {
+        MF_GLOAD(lrt, lkt, ra1, rb1)
+        MF_ADVANCE_LOAD()
+    }
+    MF_SSTORE(0, ra0, rb0)
+    __syncthreads();
+    int cur = 0;
+#define MF_STEP(RA_LD, RB_LD, RA_ST, RB_ST)                                                \
+    {                                                                                      \
+        if (it + 2 < n_it) {                                                               \
+            MF_GLOAD(lrt, lkt, RA_LD, RB_LD)                                               \
+            MF_ADVANCE_LOAD()                                                              \
+        }                                                                                  \
+        MF_COMPUTE_AND_EPILOGUE()                                                          \
+        if (it + 1 < n_it) {                                                               \
+            MF_SSTORE(cur ^ 1, RA_ST, RB_ST)                                               \
+        }                                                                                  \
+        __syncthreads();                                                                   \
+        cur ^= 1;                                                                          \
+        if (++kt == KT) {                                                                  \
+            kt = 0;                                                                        \
+            ++rt;                                                                          \
+        }                                                                                  \
+        ++it;                                                                              \
+    }
+    auto compute_and_epilogue = [&]() {
+        const float* A = As + cur * MF_BM * MF_BK;
+        const float* B = Bs + cur * MF_BN * MF_BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // two 16-wide k-steps per 32-k tile; lane half fh takes chunk 2ks+fh
+            const v8bf bh = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 2 * ks + fh));
+            const v8bf bl = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 4 + 2 * ks + fh));
+            v8bf ah[4], al[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ah[m] = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 2 * ks + fh));
+                al[m] = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 4 + 2 * ks + fh));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                // (h_x + l_x).(h_q + l_q): small terms first
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+            }
+        }
+        if (kt == KT - 1) {
+            // ---------------- epilogue of row tile rt ----------------
+            const int64_t row0 = rt * MF_BM;
+            if constexpr (METRIC == CSS_METRIC_L2) {
+                // s = 2 x.q - ||x||^2  (||q||^2 is added in the final merge)
+                if (tid < MF_BM) xn2s[tid] = row0 + tid < ntotal ? xnorm2[row0 + tid] : 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[m][r] = 2.f * acc[m][r] - xn2s[32 * m + (r & 3) + 8 * (r >> 2) + 4 * fh];
+            }
+            thr_g = key2f(__hip_atomic_load(&gthr[q_base + jq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float thr_l = ls[jq * k + (k - 1)];
+            const float thr = fmaxf(thr_l, thr_g);
+            const bool full_tile = row0 + MF_BM <= ntotal;
+            bool anyp = false;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) anyp |= acc[m][r] >= thr;
+            anyp &= jq + q_base < nq_real;
+            // Block-uniform vote (one extra barrier per row tile): the slow path borrows the
+            // just-consumed A staging buffer as its scratch, which keeps the block under 80 KiB
+            // of LDS (two blocks per CU: one block's MFMAs overlap the other's staging).
+            int* fl = eflag + (int)(rt & 1);
+            if (__ballot(anyp) != 0ull && lane == 0) *fl = 1;
+            __syncthreads();
+            if (*fl) {
+                if (tid == 0) eflag[(int)((rt + 1) & 1)] = 0;  // re-arm the other flag for the next row tile
+                float* S = const_cast<float*>(As + cur * MF_BM * MF_BK) + wave * (32 * 32);
+                bool changed = false;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
+                    for (int rr = 0; rr < 32; ++rr) {
+                        const int64_t row = row0 + 32 * m + rr;
+                        const float sv = S[rr * 32 + fr];
+                        const bool pass = fh == 0 && (full_tile || row < ntotal) && q_base + jq < nq_real &&
+                                          sv >= thr_l && sv >= thr_g;
+                        unsigned long long mk = __ballot(pass);
+                        if (mk == 0ull) continue;
+                        while (mk) {
+                            const int src = __ffsll((long long)mk) - 1;
+                            mk &= mk - 1;
+                            const float cs = __shfl(sv, src);
+                            const int cj = wave * 32 + src;
+                            const bool ins = wave_insert<uint32_t>(ls + cj * k, li + cj * k, k, cs, (uint32_t)row, lane);
+                            changed |= ins && (fr == src);
+                        }
+                        thr_l = ls[jq * k + (k - 1)];
+                    }
+                }
+                if (changed && fh == 0 && thr_l > thr_g) atomicMax(&gthr[q_base + jq], f2key(thr_l));
+            } else if (tid == 0) {
+                eflag[(int)((rt + 1) & 1)] = 0;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
+
+    };
+#define MF_COMPUTE_AND_EPILOGUE() compute_and_epilogue();
+    for (int64_t it = 0; it < n_it;) {
+        // step `it` (even): set 0 was stored last step; it receives the loads of step it+2
+        MF_STEP(ra0, rb0, ra1, rb1)
+        if (it >= n_it) break;
+        MF_STEP(ra1, rb1, ra0, rb0)
+    }
+#undef MF_STEP
+#undef MF_ADVANCE_LOAD
+#undef MF_COMPUTE_AND_EPILOGUE
+#undef MF_GLOAD
+#undef MF_SSTORE
+    // part layout: [q][strip][k]
+    for (int i = tid; i < MF_BN * k; i += 256) {
+        const int j = i / k, p = i - j * k;
+        if (q_base + j < nq_real) {
+            const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
+            part_s[o] = ls[i];
+            part_i[o] = li[i];
+        }
+    }
+}
+
+
+
+// qpad [nq_pad][dpad] fp32 -> qsplit [nq_pad][dpad/32][h(32) | l(32)] bf16
+__global__ void k_split_queries(const float* __restrict__ qpad, unsigned short* __restrict__ qsplit, int64_t n, int dpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // element index
+    if (i >= n * dpad) return;
+    const int64_t row = i / dpad;
+    const int c = (int)(i - row * dpad), kt = c >> 5, kk = c & 31;
+    const float x = qpad[i];
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    unsigned short* o = qsplit + (row * (dpad >> 5) + kt) * 64;
+    o[kk] = __builtin_bit_cast(unsigned short, h);
+    o[32 + kk] = __builtin_bit_cast(unsigned short, l);
 }
 
 // ------------------------------------------------------------------ final merge
@@ -765,15 +1033,22 @@ int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb
 }
 
 
+// Query batches: split-bf16 MFMA (default) or exact fp32 MFMA (CSS_KNN_BATCH=fp32, verification).
+int g_knn_batch_split = -1;
+
 template <int METRIC>
 int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
+    if (g_knn_batch_split < 0) {
+        const char* m = getenv("CSS_KNN_BATCH");
+        g_knn_batch_split = (m && std::string(m) == "fp32") ? 0 : 1;
+    }
     const int nq_pad = (nq + MF_BN - 1) / MF_BN * MF_BN;
     const int nqtiles = nq_pad / MF_BN;
     const int64_t ntiles = (ix->ntotal + MF_BM - 1) / MF_BM;
     // one block per CU (LDS bound); strips in multiples of 8 for the XCD-aware block decode
     int nstrips = std::max(8, ix->num_cus / nqtiles / 8 * 8);
     nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
-    const int64_t tps = (ntiles + nstrips - 1) / nstrips;
+    int64_t tps = (ntiles + nstrips - 1) / nstrips;
     int rc;
     if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
     if (nq_pad > nq)
@@ -781,10 +1056,32 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad,
                        host_f2key(-INFINITY));
     CSS_LAUNCH_CHECK();
-    const size_t lds = (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 + (size_t)MF_BN * k * 8;
-    auto kern = k_scan_mfma<METRIC>;
-    CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
+    // fp32 kernel: staging + per-wave scratch + lists (1 block/CU); split kernel: no private scratch,
+    // and when its footprint is <= 80 KiB two blocks share a CU (strips doubled accordingly)
+    const size_t lds = g_knn_batch_split
+                           ? (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + MF_BM + 4) * 4 + (size_t)MF_BN * k * 8
+                           : (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 + (size_t)MF_BN * k * 8;
+    if (g_knn_batch_split && lds <= 80 * 1024) {
+        nstrips = std::max(8, 2 * ix->num_cus / nqtiles / 8 * 8);
+        nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
+        tps = (ntiles + nstrips - 1) / nstrips;
+        if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
+    }
+    if (g_knn_batch_split) {
+        if ((rc = grow(&ix->qsplit, &ix->qsplit_cap, (size_t)nq_pad * ix->dpad * 2)) != CSS_OK) return rc;
+        const int64_t ne = (int64_t)nq_pad * ix->dpad;
+        hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ix->qpad, ix->qsplit,
+                           (int64_t)nq_pad, ix->dpad);
+        CSS_LAUNCH_CHECK();
+        auto kern = k_scan_mfma_split<METRIC>;
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ProfScope ps("knn_scan_mfma", st);
+        hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
+                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+        CSS_LAUNCH_CHECK();
+    } else {
+        auto kern = k_scan_mfma<METRIC>;
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps("knn_scan_mfma", st);
         hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qpad, nq,
                            ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
@@ -879,7 +1176,7 @@ int css_index_free(css_index* ix) {
     if (!ix) return CSS_OK;
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->xb, ix->xnorm2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr,
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

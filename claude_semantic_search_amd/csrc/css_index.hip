@@ -477,19 +477,25 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
 // throughput at fp32-grade error (operand truncation 2^-17, random sign over 768 terms:
 // ~1e-7 on unit vectors, same order as fp32 accumulation order effects).  The index stays
 // fp32 in HBM; queries are pre-split once per search (k_split_queries).
-template <int METRIC>
-__global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restrict__ xb, const float* __restrict__ xnorm2,
+// NW waves x 32 queries = BN query columns per block; every wave holds MT 32-row tiles (BM = 32*MT rows).
+// (NW, MT) = (4, 4): 128x128 tile, <= 80 KiB LDS, two blocks per CU; (8, 8): 256x256 tile, one block of
+// 8 waves per CU, half the operand bytes per MFMA (the CU's L2->LDS path is the scarce resource).
+template <int METRIC, int NW, int MT>
+__global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __restrict__ xb, const float* __restrict__ xnorm2,
                                                       const unsigned short* __restrict__ qsplit, int nq_real, int64_t ntotal,
                                                       int dpad, int k, int nstrips, int nqtiles,
                                                       int64_t tiles_per_strip, int* __restrict__ gthr,
                                                       float* __restrict__ part_s, uint32_t* __restrict__ part_i) {
+    constexpr int NT = 64 * NW, BM = 32 * MT, BN = 32 * NW;
+    constexpr int APASS = BM * 4 / NT;   // A staging passes (rows per pass = NT/4)
+    static_assert(NW <= MT && APASS >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);                 // [2][128][32]
-    float* Bs = As + 2 * MF_BM * MF_BK;                         // [2][128][32]
-    float* xn2s = Bs + 2 * MF_BN * MF_BK;                       // [128]
-    int* eflag = reinterpret_cast<int*>(xn2s + MF_BM);          // [2] slow-path votes (alternating)
-    float* ls = xn2s + MF_BM + 4;                               // [128][k]
-    uint32_t* li = reinterpret_cast<uint32_t*>(ls + MF_BN * k);  // [128][k]
+    float* As = reinterpret_cast<float*>(smem);                 // [2][BM][32]
+    float* Bs = As + 2 * BM * MF_BK;                         // [2][BM][32]
+    float* xn2s = Bs + 2 * BN * MF_BK;                       // [BM]
+    int* eflag = reinterpret_cast<int*>(xn2s + BM);          // [2] slow-path votes (alternating)
+    float* ls = xn2s + BM + 4;                               // [BM][k]
+    uint32_t* li = reinterpret_cast<uint32_t*>(ls + BN * k);  // [BM][k]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware decode: blocks l, l+8, l+16, ... (same XCD under round-robin dispatch)
@@ -497,19 +503,19 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
     const int l = blockIdx.x;
     const int strip = (l / (8 * nqtiles)) * 8 + (l & 7);
     const int qtile = (l >> 3) % nqtiles;
-    const int64_t ntiles = (ntotal + MF_BM - 1) / MF_BM;
+    const int64_t ntiles = (ntotal + BM - 1) / BM;
     const int64_t t_begin = (int64_t)strip * tiles_per_strip;
     const int64_t t_end = min(t_begin + tiles_per_strip, ntiles);
-    const int q_base = qtile * MF_BN;
+    const int q_base = qtile * BN;
 
-    for (int i = tid; i < MF_BN * k; i += 256) {
+    for (int i = tid; i < BN * k; i += NT) {
         ls[i] = -INFINITY;
         li[i] = kInvalidRow;
     }
     if (tid < 2) eflag[tid] = 0;
     __syncthreads();
     if (t_begin >= t_end) {
-        for (int i = tid; i < MF_BN * k; i += 256) {
+        for (int i = tid; i < BN * k; i += NT) {
             const int j = i / k, p = i - j * k;
             if (q_base + j < nq_real) {
                 const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
@@ -525,26 +531,26 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
     // staging map: thread -> (row = (tid>>3) + 32*i, 16-B chunk = tid&7), i = 0..3
     const int srow = tid >> 3, schunk = tid & 7;
     const int arow = tid >> 2, akg = tid & 3;
-    v4f ra0[4], rb0[4], ra1[4], rb1[4];  // two prefetch sets: loads run two K-steps ahead
+    v4f ra0[2 * APASS], rb0[4], ra1[2 * APASS], rb1[4];  // two prefetch sets: loads run two K-steps ahead
 
 // (macros, not lambdas: by-reference lambda captures left ra/rb in scratch memory)
 // A: thread -> row (tid>>2) + 64*i, 8 consecutive k = (tid&3)*8 (two float4), converted here to
 // the bf16 pair (h, l) with x ~= h + l (16 significant bits); LDS row = [h k0..31 | l k0..31].
 // B: the pre-split queries are copied 16 B at a time (thread -> row (tid>>3) + 32*i, chunk tid&7).
 #define MF_GLOAD(RT, KT, RA, RB)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-        int64_t row_ = (RT) * MF_BM + arow + 64 * i;                                                         \
+    _Pragma("unroll") for (int i = 0; i < APASS; ++i) {                                                      \
+        int64_t row_ = (RT) * BM + arow + (NT / 4) * i;                                                         \
         row_ = row_ < ntotal ? row_ : ntotal - 1;                                                            \
         const float* p_ = xb + row_ * (int64_t)dpad + (KT) * MF_BK + akg * 8;                                \
         RA[2 * i] = *reinterpret_cast<const v4f*>(p_);                                                       \
         RA[2 * i + 1] = *reinterpret_cast<const v4f*>(p_ + 4);                                               \
     }                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-        RB[i] = *reinterpret_cast<const v4f*>(qsplit + ((int64_t)(q_base + srow + 32 * i) * (dpad / MF_BK) + (KT)) * 64 + \
+        RB[i] = *reinterpret_cast<const v4f*>(qsplit + ((int64_t)(q_base + srow + (NT / 8) * i) * (dpad / MF_BK) + (KT)) * 64 + \
                                               schunk * 8);                                                   \
     }
 #define MF_SSTORE(BUF, RA, RB)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+    _Pragma("unroll") for (int i = 0; i < APASS; ++i) {                                                      \
         v8bf h_, l_;                                                                                         \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
             const float x_ = j < 4 ? RA[2 * i][j] : RA[2 * i + 1][j - 4];                                    \
@@ -552,17 +558,17 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
             h_[j] = hb_;                                                                                     \
             l_[j] = (__bf16)(x_ - (float)hb_);                                                               \
         }                                                                                                    \
-        char* A_ = reinterpret_cast<char*>(As + (BUF) * MF_BM * MF_BK);                                      \
-        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + 64 * i, akg) * 4) = h_;                                  \
-        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + 64 * i, 4 + akg) * 4) = l_;                              \
+        char* A_ = reinterpret_cast<char*>(As + (BUF) * BM * MF_BK);                                      \
+        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + (NT / 4) * i, akg) * 4) = h_;                                  \
+        *reinterpret_cast<v8bf*>(A_ + mf_swz(arow + (NT / 4) * i, 4 + akg) * 4) = l_;                              \
     }                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-        *reinterpret_cast<v4f*>(Bs + (BUF) * MF_BN * MF_BK + mf_swz(srow + 32 * i, schunk)) = RB[i];         \
+        *reinterpret_cast<v4f*>(Bs + (BUF) * BN * MF_BK + mf_swz(srow + (NT / 8) * i, schunk)) = RB[i];         \
     }
 
-    f32x16 acc[4];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
@@ -609,36 +615,32 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
         ++it;                                                                              \
     }
     auto compute_and_epilogue = [&]() {
-        const float* A = As + cur * MF_BM * MF_BK;
-        const float* B = Bs + cur * MF_BN * MF_BK;
+        const float* A = As + cur * BM * MF_BK;
+        const float* B = Bs + cur * BN * MF_BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {  // two 16-wide k-steps per 32-k tile; lane half fh takes chunk 2ks+fh
             const v8bf bh = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 2 * ks + fh));
             const v8bf bl = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 4 + 2 * ks + fh));
-            v8bf ah[4], al[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                ah[m] = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 2 * ks + fh));
-                al[m] = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 4 + 2 * ks + fh));
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
+                const v8bf ah = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 2 * ks + fh));
+                const v8bf al = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 4 + 2 * ks + fh));
                 // (h_x + l_x).(h_q + l_q): small terms first
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
             }
         }
         if (kt == KT - 1) {
             // ---------------- epilogue of row tile rt ----------------
-            const int64_t row0 = rt * MF_BM;
+            const int64_t row0 = rt * BM;
             if constexpr (METRIC == CSS_METRIC_L2) {
                 // s = 2 x.q - ||x||^2  (||q||^2 is added in the final merge)
-                if (tid < MF_BM) xn2s[tid] = row0 + tid < ntotal ? xnorm2[row0 + tid] : 0.f;
+                if (tid < BM) xn2s[tid] = row0 + tid < ntotal ? xnorm2[row0 + tid] : 0.f;
                 __syncthreads();
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         acc[m][r] = 2.f * acc[m][r] - xn2s[32 * m + (r & 3) + 8 * (r >> 2) + 4 * fh];
@@ -646,10 +648,10 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
             thr_g = key2f(__hip_atomic_load(&gthr[q_base + jq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             float thr_l = ls[jq * k + (k - 1)];
             const float thr = fmaxf(thr_l, thr_g);
-            const bool full_tile = row0 + MF_BM <= ntotal;
+            const bool full_tile = row0 + BM <= ntotal;
             bool anyp = false;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) anyp |= acc[m][r] >= thr;
             anyp &= jq + q_base < nq_real;
@@ -661,10 +663,10 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
             __syncthreads();
             if (*fl) {
                 if (tid == 0) eflag[(int)((rt + 1) & 1)] = 0;  // re-arm the other flag for the next row tile
-                float* S = const_cast<float*>(As + cur * MF_BM * MF_BK) + wave * (32 * 32);
+                float* S = const_cast<float*>(As + cur * BM * MF_BK) + wave * (32 * 32);
                 bool changed = false;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
                     for (int rr = 0; rr < 32; ++rr) {
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
                 eflag[(int)((rt + 1) & 1)] = 0;
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
         }
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_mfma_split(const float* __restr
 #undef MF_GLOAD
 #undef MF_SSTORE
     // part layout: [q][strip][k]
-    for (int i = tid; i < MF_BN * k; i += 256) {
+    for (int i = tid; i < BN * k; i += NT) {
         const int j = i / k, p = i - j * k;
         if (q_base + j < nq_real) {
             const size_t o = ((size_t)(q_base + j) * nstrips + strip) * k + p;
@@ -1042,13 +1044,22 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
         const char* m = getenv("CSS_KNN_BATCH");
         g_knn_batch_split = (m && std::string(m) == "fp32") ? 0 : 1;
     }
-    const int nq_pad = (nq + MF_BN - 1) / MF_BN * MF_BN;
-    const int nqtiles = nq_pad / MF_BN;
-    const int64_t ntiles = (ix->ntotal + MF_BM - 1) / MF_BM;
-    // one block per CU (LDS bound); strips in multiples of 8 for the XCD-aware block decode
-    int nstrips = std::max(8, ix->num_cus / nqtiles / 8 * 8);
+    const bool split = g_knn_batch_split != 0;
+    const bool big = split && nq > 128 && k <= 14;  // 256x256 tiles (8 waves) for real batches
+    const int BMs = big ? 256 : MF_BM, BNs = big ? 256 : MF_BN;
+    const int nq_pad = (nq + BNs - 1) / BNs * BNs;  // <= nq + 255 (qpad / gthr have 256 rows of slack)
+    const int nqtiles = nq_pad / BNs;
+    const int64_t ntiles = (ix->ntotal + BMs - 1) / BMs;
+    // fp32 kernel: staging + per-wave scratch + lists; split kernels: staging + lists (the slow-path
+    // scratch borrows a staging buffer).  <= 80 KiB means two blocks share a CU.
+    const size_t lds = split ? (size_t)(2 * BMs * MF_BK + 2 * BNs * MF_BK + BMs + 4) * 4 + (size_t)BNs * k * 8
+                             : (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 +
+                                   (size_t)MF_BN * k * 8;
+    const int bpc = (split && !big && lds <= 80 * 1024) ? 2 : 1;
+    // strips in multiples of 8 for the XCD-aware block decode
+    int nstrips = std::max(8, bpc * ix->num_cus / nqtiles / 8 * 8);
     nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
-    int64_t tps = (ntiles + nstrips - 1) / nstrips;
+    const int64_t tps = (ntiles + nstrips - 1) / nstrips;
     int rc;
     if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
     if (nq_pad > nq)
@@ -1056,28 +1067,24 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad,
                        host_f2key(-INFINITY));
     CSS_LAUNCH_CHECK();
-    // fp32 kernel: staging + per-wave scratch + lists (1 block/CU); split kernel: no private scratch,
-    // and when its footprint is <= 80 KiB two blocks share a CU (strips doubled accordingly)
-    const size_t lds = g_knn_batch_split
-                           ? (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + MF_BM + 4) * 4 + (size_t)MF_BN * k * 8
-                           : (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 + (size_t)MF_BN * k * 8;
-    if (g_knn_batch_split && lds <= 80 * 1024) {
-        nstrips = std::max(8, 2 * ix->num_cus / nqtiles / 8 * 8);
-        nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
-        tps = (ntiles + nstrips - 1) / nstrips;
-        if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
-    }
-    if (g_knn_batch_split) {
+    if (split) {
         if ((rc = grow(&ix->qsplit, &ix->qsplit_cap, (size_t)nq_pad * ix->dpad * 2)) != CSS_OK) return rc;
         const int64_t ne = (int64_t)nq_pad * ix->dpad;
         hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ix->qpad, ix->qsplit,
                            (int64_t)nq_pad, ix->dpad);
         CSS_LAUNCH_CHECK();
-        auto kern = k_scan_mfma_split<METRIC>;
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps("knn_scan_mfma", st);
-        hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+        if (big) {
+            auto kern = k_scan_mfma_split<METRIC, 8, 8>;
+            CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(512), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
+                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+        } else {
+            auto kern = k_scan_mfma_split<METRIC, 4, 4>;
+            CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
+                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+        }
         CSS_LAUNCH_CHECK();
     } else {
         auto kern = k_scan_mfma<METRIC>;
@@ -1106,9 +1113,9 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     CSS_REQUIRE(nq >= 0 && nq < (1 << 24), "css_index_search: nq=%lld out of range", (long long)nq);
     if (nq == 0) return CSS_OK;
     int rc;
-    if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 128) * ix->dpad)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 128)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 128)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 256) * ix->dpad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     // query prep: same row kernel as ingest (normalise, zero pad, squared norm)
     {
         const int64_t blocks = (nq + 3) / 4;

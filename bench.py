@@ -329,9 +329,22 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_knn(args, log)
-    if rank == 0 and world == 1 and not args.no_encoder:
-        index.close()  # free the 30 GB shard before the encoder leg
-        extra["encode"] = bench_encoder(args, dev, log)
+    if not args.no_encoder:
+        index.close()  # free the shard before the encoder leg
+        if world == 1:
+            extra["encode"] = bench_encoder(args, dev, log)
+        else:
+            # encoder: replicas only (weights replicated, one batch per rank, no collective in the path)
+            args.no_cpu_baseline = True
+            enc = bench_encoder(args, dev, (lambda m: None) if rank else log)
+            t = torch.tensor([enc["chunks_per_s"], enc["ms_per_batch"]], dtype=torch.float64, device=dev)
+            tsum = t.clone()
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            enc["chunks_per_s_all_ranks"] = float(tsum[0].item())
+            enc["ms_per_batch_max_over_ranks"] = float(t[1].item())
+            enc["parallelism"] = f"{world} replicas, no collective"
+            extra["encode"] = enc
 
     if world > 1:
         dist.barrier()

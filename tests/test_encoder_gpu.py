@@ -102,3 +102,44 @@ def test_invalid_inputs_fail_loudly():
         enc.encode_ids([[0] + [5] * 400 + [2]])  # longer than max_seq_len
     with pytest.raises(FileNotFoundError):
         MpnetEncoder("all-mpnet-base-v2")        # no weights offline: never silently synthetic
+
+
+def test_committed_goldens_2layer_and_probes():
+    """HIP encoder vs the committed oracle goldens (tests/golden/encoder_2layer.npz): pooled
+    embeddings and the layer-0 probes (embedding LN, attention block output, layer output)."""
+    from pathlib import Path
+
+    from oracle import mpnet_oracle as mo
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "encoder_2layer.npz")
+    lengths = g["lengths"].tolist()
+    cfg = mo.MpnetCfg(num_layers=2)
+    batch = mo.synth_batch(cfg, lengths, seed=int(g["bseed"]))
+    for mode, tol, ptol in (("fp32", 1e-4, 2e-4), ("bf16", 2e-2, 6e-2)):
+        enc = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute=mode, cfg_overrides={"num_layers": 2})
+        out = enc.encode_ids(batch)
+        assert np.abs(out - g["emb"]).max() < tol and ((out * g["emb"]).sum(1)).min() > 1 - 1e-3
+        enc.close()
+        enc1 = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute=mode, cfg_overrides={"num_layers": 1})
+        enc1.encode_ids(batch)
+        T = sum(lengths)
+        x = enc1.debug_read("x32", (T, 768))  # layer-0 output = final hidden state of the 1-layer model
+        off = np.cumsum([0] + lengths)
+        got = np.stack([np.stack([x[off[i], :8], x[off[i + 1] - 1, :8]]) for i in range(len(lengths))])
+        assert np.abs(got - g["ffn_out"]).max() < ptol, (mode, np.abs(got - g["ffn_out"]).max())
+        enc1.close()
+
+
+def test_committed_goldens_12layer():
+    from pathlib import Path
+
+    from oracle import mpnet_oracle as mo
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "encoder_12layer.npz")
+    cfg = mo.MpnetCfg()
+    batch = mo.synth_batch(cfg, g["lengths"].tolist(), seed=int(g["bseed"]))
+    enc = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute="bf16")
+    out = enc.encode_ids(batch)
+    cos = (out * g["emb"]).sum(1)
+    assert cos.min() > 1 - 1e-3, cos
+    enc.close()

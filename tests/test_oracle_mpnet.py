@@ -78,3 +78,17 @@ def test_synth_weights_spec():
     assert abs(float(w["encoder.layer.0.attention.LayerNorm.weight"].mean()) - 1.0) < 2e-2
     n = sum(v.numel() for v in w.values())
     assert n == 30527 * 768 + 514 * 768 + 2 * 768 + 32 * 12 + (4 * (768 * 768 + 768) + 2 * 768 * 3072 + 3072 + 768 + 4 * 768)
+
+
+def test_committed_bucket_table_and_goldens_reproduce():
+    from pathlib import Path
+
+    gold = Path(__file__).resolve().parent / "golden"
+    tab = np.load(gold / "rel_bucket_table.npy")
+    rel = torch.arange(-511, 512)
+    assert np.array_equal(tab, mo.relative_position_bucket(rel, 32).numpy().astype(np.int8))
+    g = np.load(gold / "encoder_2layer.npz")
+    cfg = mo.MpnetCfg(num_layers=2)
+    lengths = g["lengths"].tolist()[:3]  # the short ones keep the CPU suite fast
+    out = mo.encode(mo.synth_weights(cfg, int(g["wseed"])), cfg, mo.synth_batch(cfg, g["lengths"].tolist(), seed=int(g["bseed"]))[:3])
+    assert np.abs(out - g["emb"][:3]).max() < 2e-6

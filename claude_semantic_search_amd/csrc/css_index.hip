@@ -649,12 +649,16 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
             float thr_l = ls[jq * k + (k - 1)];
             const float thr = fmaxf(thr_l, thr_g);
             const bool full_tile = row0 + BM <= ntotal;
-            bool anyp = false;
+            const bool colok = jq + q_base < nq_real;
+            unsigned hitm = 0;  // bit m: this lane's query has a candidate in 32-row tile m
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                bool h = false;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) anyp |= acc[m][r] >= thr;
-            anyp &= jq + q_base < nq_real;
+                for (int r = 0; r < 16; ++r) h |= acc[m][r] >= thr;
+                hitm |= (h && colok) ? (1u << m) : 0u;
+            }
+            const bool anyp = hitm != 0;
             // Block-uniform vote (one extra barrier per row tile): the slow path borrows the
             // just-consumed A staging buffer as its scratch, which keeps the block under 80 KiB
             // of LDS (two blocks per CU: one block's MFMAs overlap the other's staging).
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
                 bool changed = false;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
+                    if (__ballot((hitm >> m) & 1u) == 0ull) continue;  // wave-uniform: no candidate in this 32-row tile
 #pragma unroll
                     for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = acc[m][r];
                     for (int rr = 0; rr < 32; ++rr) {

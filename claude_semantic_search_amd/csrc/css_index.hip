@@ -531,7 +531,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
     // staging map: thread -> (row = (tid>>3) + 32*i, 16-B chunk = tid&7), i = 0..3
     const int srow = tid >> 3, schunk = tid & 7;
     const int arow = tid >> 2, akg = tid & 3;
-    v4f ra0[2 * APASS], rb0[4], ra1[2 * APASS], rb1[4];  // two prefetch sets: loads run two K-steps ahead
+    // global loads run two K-steps ahead in two register sets when one wave per SIMD must hide the
+    // whole L2/HBM latency (NW = 4); with two waves per SIMD (NW = 8) one set is enough and the
+    // freed registers let the compiler read LDS fragments ahead of the MFMAs
+    constexpr bool PF2 = NW < 8;
+    v4f ra0[2 * APASS], rb0[4], ra1[PF2 ? 2 * APASS : 1], rb1[PF2 ? 4 : 1];
 
 // (macros, not lambdas: by-reference lambda captures left ra/rb in scratch memory)
 // A: thread -> row (tid>>2) + 64*i, 8 consecutive k = (tid&3)*8 (two float4), converted here to
@@ -589,22 +593,48 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
     }
     MF_GLOAD(lrt, lkt, ra0, rb0)
     MF_ADVANCE_LOAD()
+    MF_SSTORE(0, ra0, rb0)
     if (n_it > 1) {
-        MF_GLOAD(lrt, lkt, ra1, rb1)
+        MF_GLOAD(lrt, lkt, ra0, rb0)  // tile 1 (PF2: set 0 again, tile 2 goes to set 1 below)
         MF_ADVANCE_LOAD()
     }
-    MF_SSTORE(0, ra0, rb0)
+    if constexpr (PF2) {
+        if (n_it > 2) {
+            MF_GLOAD(lrt, lkt, ra1, rb1)
+            MF_ADVANCE_LOAD()
+        }
+    }
     __syncthreads();
     int cur = 0;
-#define MF_STEP(RA_LD, RB_LD, RA_ST, RB_ST)                                                \
+// PF2 step: compute tile it | store tile it+1 (set RA/RB) to LDS | reload that set with tile it+3
+#define MF_STEP2(RA, RB)                                                                   \
     {                                                                                      \
-        if (it + 2 < n_it) {                                                               \
-            MF_GLOAD(lrt, lkt, RA_LD, RB_LD)                                               \
-            MF_ADVANCE_LOAD()                                                              \
-        }                                                                                  \
         MF_COMPUTE_AND_EPILOGUE()                                                          \
         if (it + 1 < n_it) {                                                               \
-            MF_SSTORE(cur ^ 1, RA_ST, RB_ST)                                               \
+            MF_SSTORE(cur ^ 1, RA, RB)                                                     \
+        }                                                                                  \
+        if (it + 3 < n_it) {                                                               \
+            MF_GLOAD(lrt, lkt, RA, RB)                                                     \
+            MF_ADVANCE_LOAD()                                                              \
+        }                                                                                  \
+        __syncthreads();                                                                   \
+        cur ^= 1;                                                                          \
+        if (++kt == KT) {                                                                  \
+            kt = 0;                                                                        \
+            ++rt;                                                                          \
+        }                                                                                  \
+        ++it;                                                                              \
+    }
+// single-set step: compute tile it | store tile it+1 | load tile it+2 into the same set
+#define MF_STEP1()                                                                         \
+    {                                                                                      \
+        MF_COMPUTE_AND_EPILOGUE()                                                          \
+        if (it + 1 < n_it) {                                                               \
+            MF_SSTORE(cur ^ 1, ra0, rb0)                                                   \
+        }                                                                                  \
+        if (it + 2 < n_it) {                                                               \
+            MF_GLOAD(lrt, lkt, ra0, rb0)                                                   \
+            MF_ADVANCE_LOAD()                                                              \
         }                                                                                  \
         __syncthreads();                                                                   \
         cur ^= 1;                                                                          \
@@ -621,10 +651,17 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
         for (int ks = 0; ks < 2; ++ks) {  // two 16-wide k-steps per 32-k tile; lane half fh takes chunk 2ks+fh
             const v8bf bh = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 2 * ks + fh));
             const v8bf bl = *reinterpret_cast<const v8bf*>(B + mf_swz(jq, 4 + 2 * ks + fh));
+            // A fragments are read one 32-row tile ahead of the MFMAs that consume them, so the
+            // LDS latency hides behind the previous tile's four MFMAs.
+            v8bf ah_n = *reinterpret_cast<const v8bf*>(A + mf_swz(fr, 2 * ks + fh));
+            v8bf al_n = *reinterpret_cast<const v8bf*>(A + mf_swz(fr, 4 + 2 * ks + fh));
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const v8bf ah = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 2 * ks + fh));
-                const v8bf al = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * m + fr, 4 + 2 * ks + fh));
+                const v8bf ah = ah_n, al = al_n;
+                if (m + 1 < MT) {
+                    ah_n = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * (m + 1) + fr, 2 * ks + fh));
+                    al_n = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * (m + 1) + fr, 4 + 2 * ks + fh));
+                }
                 // (h_x + l_x).(h_q + l_q): small terms first
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
@@ -704,13 +741,22 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
 
     };
 #define MF_COMPUTE_AND_EPILOGUE() compute_and_epilogue();
-    for (int64_t it = 0; it < n_it;) {
-        // step `it` (even): set 0 was stored last step; it receives the loads of step it+2
-        MF_STEP(ra0, rb0, ra1, rb1)
-        if (it >= n_it) break;
-        MF_STEP(ra1, rb1, ra0, rb0)
+    // Invariant at the top of step `it`: LDS buf[cur] holds tile it; register set S(it+1) holds tile
+    // it+1 (already loaded); PF2: set S(it+2) holds tile it+2.  S alternates 0,1 for PF2, is always 0 otherwise.
+    if constexpr (PF2) {
+        for (int64_t it = 0; it < n_it;) {
+            // tile it+1 is in set 0 when `it` is even; tile it+3 is loaded into that set after it is stored
+            MF_STEP2(ra0, rb0)
+            if (it >= n_it) break;
+            MF_STEP2(ra1, rb1)
+        }
+    } else {
+        for (int64_t it = 0; it < n_it;) {
+            MF_STEP1()
+        }
     }
-#undef MF_STEP
+#undef MF_STEP1
+#undef MF_STEP2
 #undef MF_ADVANCE_LOAD
 #undef MF_COMPUTE_AND_EPILOGUE
 #undef MF_GLOAD

@@ -226,16 +226,17 @@ int ensure_acts(css_encoder* e, int T, int B) {
 }
 
 extern int g_gemm_dbg;
+extern int g_gemm_ring;
 // Tile shapes: 2x2 waves x (2x2) MFMA tiles = 128x128, or 2x4 waves x (4x2) tiles = 256x256
 // (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
-template <typename TIn, int EPI, int WM, int WN, int TM, int TN>
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
 int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   int num_cus, hipStream_t st, const char* prof) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    CSS_REQUIRE(N % BN == 0 && K % 32 == 0 && K / 32 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
+    CSS_REQUIRE(N % BN == 0 && K % 64 == 0 && K / 64 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
-    auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN>;
-    const size_t lds = 4 * (size_t)(BM + BN) * 64;  // 4-deep ring of 64-B-row stages
+    auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB>;
+    const size_t lds = (size_t)NST * (BM + BN) * RB;  // ring of NST stages, RB bytes of K per row
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -252,14 +253,19 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
 }
 
 int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
-int g_gemm_big_tiles = 1;  // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
+int g_gemm_big_tiles = 1;
+int g_gemm_ring = 2;       // CSS_GEMM_RING: 2 = 2 stages x 128 B rows (default: fewest barriers, measured fastest), 3 = 3 x 64 B, 4 = 4 x 64 B  // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
 
 template <typename TIn, int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                 int num_cus, hipStream_t st, const char* prof) {
-    if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0)
-        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
-    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+    if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
+        // ring shape: 4 x 64 KiB... (NST stages x RB bytes of K per row); CSS_GEMM_RING selects for A/B runs
+        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+    }
+    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
 }
 
 template <typename TIn>
@@ -358,6 +364,7 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     DeviceGuard g(device);
     if (const char* t = getenv("CSS_GEMM_TILE")) g_gemm_big_tiles = atoi(t) != 128;
     if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
+    if (const char* t = getenv("CSS_GEMM_RING")) g_gemm_ring = atoi(t);
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;

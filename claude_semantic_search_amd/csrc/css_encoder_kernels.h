@@ -166,13 +166,9 @@ enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 template <typename TIn>
 struct GemmTraits;
 template <>
-struct GemmTraits<bf16_t> {
-    static constexpr int BK = 32;
-};
+struct GemmTraits<bf16_t> {};
 template <>
-struct GemmTraits<float> {
-    static constexpr int BK = 16;
-};
+struct GemmTraits<float> {};
 
 __device__ __forceinline__ int swz64_byte(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -202,21 +198,24 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // PPW LDS-DMA instructions per stage and E unconditional stores per tile (rows beyond M land
 // in the slack rows every activation buffer has).
 // dbg: timing experiments only (bit0 skip epilogue, bit1 skip MFMA, bit2 skip loads).
-template <typename TIn, int EPI, int WM, int WN, int TM, int TN>
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ Cout, int M,
                                                       int N, int K, int qscale_cols, int dbg) {
-    constexpr int BK = GemmTraits<TIn>::BK;
+    static_assert(RB == 64 || RB == 128, "stage rows are 64 or 128 bytes of K");
+    constexpr int BK = RB / (int)sizeof(TIn);  // K elements per stage
     constexpr bool BF = sizeof(TIn) == 2;
     constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-    constexpr int NST = 4;                  // ring depth
-    constexpr int PIECES = (BM + BN) / 16;  // 1-KiB LDS-DMA pieces per stage
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int RPP = 1024 / RB;             // rows per 1-KiB LDS-DMA piece (16 or 8)
+    constexpr int CPR = RB / 16;               // 16-B chunks per row (4 or 8)
+    constexpr int PIECES = (BM + BN) / RPP;    // 1-KiB LDS-DMA pieces per stage
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
     constexpr int PPW = PIECES / NW;        // LDS-DMA instructions per wave per stage
     constexpr int E = TM * TN * 4;          // store instructions per wave per tile
-    static_assert(2 * PPW + E <= 63, "vmcnt is a 6-bit counter");
+    static_assert((NST - 2) * PPW + E <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST][A_BYTES | B_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,14 +236,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
     const int total = my_ntiles * KT;
     if (total == 0) return;
 
-    const int prow = lane >> 2, pchunk = lane & 3;
+    const int prow = lane / CPR, pchunk = lane % CPR;
     const char* src[PPW];  // issue-side per-lane source pointers (current issue tile)
     int dst[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int piece = wave + NW * i;
-        const bool isA = piece < BM / 16;
-        dst[i] = (isA ? 0 : A_BYTES) + (isA ? piece : piece - BM / 16) * 1024;
+        const bool isA = piece < BM / RPP;
+        dst[i] = (isA ? 0 : A_BYTES) + (isA ? piece : piece - BM / RPP) * 1024;
     }
     auto set_src = [&](int tile_idx) {
         const int tile = xfirst + jx + tile_idx * per_x;
@@ -252,9 +251,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + NW * i;
-            const bool isA = piece < BM / 16;
-            const int trow = (isA ? piece : piece - BM / 16) * 16 + prow;
-            const int logical = pchunk ^ ((trow >> 2) & 3);
+            const bool isA = piece < BM / RPP;
+            const int trow = (isA ? piece : piece - BM / RPP) * RPP + prow;
+            const int logical = RB == 64 ? (pchunk ^ ((trow >> 2) & 3)) : (pchunk ^ ((trow >> 1) & 7));
             int grow = (isA ? r0 : c0) + trow;
             const int lim = isA ? M : N;
             grow = grow < lim ? grow : lim - 1;
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
     };
 #define GM_ISSUE(KT_, SLOT_)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                        \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * 64), \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * RB), \
                                          (__attribute__((address_space(3))) void*)(smem + (SLOT_) * STAGE + dst[i]), 16, 0, 0); \
     }
 
@@ -291,12 +290,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
     int ct_tile = 0, kt = 0;
     for (int g = 0; g < total; ++g) {
         // stage g has landed once only the younger operations are outstanding
-        const int younger = min(NST - 2, total - 1 - g);
+        const int younger = min(NST - 2, total - 1 - g);  // stages issued after stage g and still allowed in flight
         const bool stores_younger = ct_tile > 0 && kt < NST - 1;  // this tile's first stages were issued before the previous epilogue
         if (dbg & 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (stores_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + E) : "memory");  // (KT >= 3: two younger stages exist)
-        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else if (stores_younger) {
+            // (KT >= NST - 1, host check: NST-2 younger stages exist here)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW + E) : "memory");
+        } else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 4 ? 2 : 0) * PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 3 ? 1 : 0) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // all pieces of stage g landed; the slot of stage g-1 is free
         if (gi < total) {
@@ -313,14 +314,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
         const char* Bb = Ab + A_BYTES;
         if (!(dbg & 2))
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < CPR / 2; ++c) {
             v4f a[TM], b[TN];
 #pragma unroll
             for (int m = 0; m < TM; ++m)
-                a[m] = *reinterpret_cast<const v4f*>(Ab + swz64_byte(wr * (TM * 32) + 32 * m + fr, 2 * c + fh));
+                a[m] = *reinterpret_cast<const v4f*>(Ab + (RB == 64 ? swz64_byte(wr * (TM * 32) + 32 * m + fr, 2 * c + fh)
+                                                                   : swz_byte(wr * (TM * 32) + 32 * m + fr, 2 * c + fh)));
 #pragma unroll
             for (int n = 0; n < TN; ++n)
-                b[n] = *reinterpret_cast<const v4f*>(Bb + swz64_byte(wc * (TN * 32) + 32 * n + fr, 2 * c + fh));
+                b[n] = *reinterpret_cast<const v4f*>(Bb + (RB == 64 ? swz64_byte(wc * (TN * 32) + 32 * n + fr, 2 * c + fh)
+                                                                   : swz_byte(wc * (TN * 32) + 32 * n + fr, 2 * c + fh)));
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll

@@ -15,6 +15,7 @@
 #include "css_encoder_kernels.h"
 #include "../../include/css_synth.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -45,12 +46,12 @@ __global__ void k_synth_fill(float* p, size_t n, uint64_t seed, float mean, floa
 }
 
 __global__ void k_build_bias_tab(const float* __restrict__ relw, const int* __restrict__ bucket, int heads, int maxL,
-                                 float* __restrict__ tab) {
+                                 float scale, float* __restrict__ tab) {
     const int n = 2 * maxL - 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * heads) return;
     const int h = i / n, r = i - h * n;
-    tab[i] = relw[bucket[r] * heads + h];
+    tab[i] = scale * relw[bucket[r] * heads + h];  // bf16 path: log2(e) (scores in the log2 domain)
 }
 
 __global__ void k_zero_row(float* p, int n) {
@@ -186,7 +187,7 @@ int finalize_weights(css_encoder* e) {
     }
     const int n = c.heads * (2 * c.max_seq_len - 1);
     hipLaunchKernelGGL(k_build_bias_tab, dim3((n + 255) / 256), dim3(256), 0, st, e->relw, e->bucket_dev, c.heads,
-                       c.max_seq_len, e->bias_tab);
+                       c.max_seq_len, c.compute == 0 ? 1.44269504088896341f : 1.0f, e->bias_tab);
     CSS_LAUNCH_CHECK();
     CSS_HIP_TRY(hipStreamSynchronize(st));
     e->weights_ready = true;
@@ -197,6 +198,7 @@ int ensure_acts(css_encoder* e, int T, int B) {
     const css_encoder_cfg& c = e->cfg;
     const size_t H = c.hidden, F = c.ffn;
     const size_t es = c.compute == 0 ? 2 : 4;
+    T = std::max(T, 8 * B);  // pre32 also holds the [B][8][H] pooling partials
     if (T > e->cap_tokens) {
         void* ptrs[] = {e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev};
         for (void* p : ptrs)
@@ -231,7 +233,7 @@ extern int g_gemm_ring;
 // (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
 template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
 int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
-                  int num_cus, hipStream_t st, const char* prof) {
+                  float qscale, int num_cus, hipStream_t st, const char* prof) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     CSS_REQUIRE(N % BN == 0 && K % 64 == 0 && K / 64 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
@@ -247,7 +249,7 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
     grid = std::max(8, grid / 8 * 8);
     ProfScope ps(prof, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, (const TIn*)A, (const TIn*)W, bias, C, M, N, K,
-                       qscale_cols, g_gemm_dbg);
+                       qscale_cols, qscale, g_gemm_dbg);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -258,14 +260,14 @@ int g_gemm_ring = 2;       // CSS_GEMM_RING: 2 = 2 stages x 128 B rows (default:
 
 template <typename TIn, int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
-                int num_cus, hipStream_t st, const char* prof) {
+                float qscale, int num_cus, hipStream_t st, const char* prof) {
     if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
         // ring shape: 4 x 64 KiB... (NST stages x RB bytes of K per row); CSS_GEMM_RING selects for A/B runs
-        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
-        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
-        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
     }
-    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, num_cus, st, prof);
+    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
 }
 
 template <typename TIn>
@@ -286,7 +288,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         const LayerW& L = e->layers[li];
         const void* xin = BF ? e->x16 : (const void*)e->x32;
         const void* wqkv = BF ? (const void*)L.wqkv_h : (const void*)L.wqkv;
-        if ((rc = launch_gemm<TIn, EPI_QKV>(xin, wqkv, L.bqkv, e->qkv, T, 3 * H, H, H, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_QKV>(xin, wqkv, L.bqkv, e->qkv, T, 3 * H, H, H, BF ? 0.125f * 1.44269504088896341f : 0.125f, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_attention", st);
@@ -301,7 +303,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
             CSS_LAUNCH_CHECK();
         }
         const void* wo = BF ? (const void*)L.wo_h : (const void*)L.wo;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->pre32, T, H, H, 0, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->pre32, T, H, H, 0, 1.0f, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_layernorm", st);
@@ -311,10 +313,10 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         }
         xin = BF ? e->x16 : (const void*)e->x32;
         const void* w1 = BF ? (const void*)L.w1_h : (const void*)L.w1;
-        if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, e->ffn, T, F, H, 0, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, e->ffn, T, F, H, 0, 1.0f, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         const void* w2 = BF ? (const void*)L.w2_h : (const void*)L.w2;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->pre32, T, H, F, 0, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
+        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->pre32, T, H, F, 0, 1.0f, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_layernorm", st);
@@ -325,7 +327,10 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
     }
     {
         ProfScope ps("enc_pool", st);
-        hipLaunchKernelGGL(k_pool_norm<768>, dim3(B), dim3(256), 0, st, e->x32, cu, normalize, out);
+        constexpr int kPoolSlices = 8;
+        // partial sums live in pre32 (free after the last LayerNorm): [B][8][H] floats
+        hipLaunchKernelGGL(k_pool_partial<768>, dim3(B, kPoolSlices), dim3(256), 0, st, e->x32, cu, kPoolSlices, e->pre32);
+        hipLaunchKernelGGL(k_pool_final<768>, dim3(B), dim3(256), 0, st, e->pre32, cu, kPoolSlices, normalize, out);
         CSS_LAUNCH_CHECK();
     }
     return CSS_OK;

@@ -201,7 +201,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ Cout, int M,
-                                                      int N, int K, int qscale_cols, int dbg) {
+                                                      int N, int K, int qscale_cols, float qscale, int dbg) {
     static_assert(RB == 64 || RB == 128, "stage rows are 64 or 128 bytes of K");
     constexpr int BK = RB / (int)sizeof(TIn);  // K elements per stage
     constexpr bool BF = sizeof(TIn) == 2;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
                                 }
                             }
                             if constexpr (EPI == EPI_QKV) {
-                                const float sc = col < qscale_cols ? 0.125f : 1.0f;  // qscale_cols is a multiple of 4
+                                const float sc = col < qscale_cols ? qscale : 1.0f;  // qscale_cols is a multiple of 4
                                 v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
                             }
                             if constexpr (EPI == EPI_RESID || !BF) {
@@ -421,8 +421,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 // cross-half exchange); O^T = V^T.P^T takes P^T straight from the accumulator
 // registers as the B operand (k order permuted: element j of lane half h is key
 // 16s + 8(j>>2) + 4h + (j&3)); the matching V^T fragments come from a row-major V
-// tile in LDS through ds_read_b64_tr_b16.  q is pre-scaled by 1/8 in the QKV
-// epilogue.  bias_tab[h][rel + (maxL-1)] holds W_rel[bucket(rel)][h], rel = key - query.
+// tile in LDS through ds_read_b64_tr_b16.  q is pre-scaled by log2(e)/8 in the QKV
+// epilogue and bias_tab[h][rel + (maxL-1)] = log2(e) * W_rel[bucket(rel)][h] (rel = key - query):
+// scores live in the log2 domain.
 template <int HD>
 __global__ __launch_bounds__(256) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,
@@ -502,31 +503,45 @@ __global__ __launch_bounds__(256) void k_attention_bf16(const bf16_t* __restrict
                 const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), qf[ks], s, 0, 0, 0);
             }
-            // bias + key mask, tile max
+            // bias (+ key mask on the sequence's last, partial tile only), tile max.
+            // Scores are in the log2 domain: q was pre-scaled by log2(e)/8 and bias_tab by log2(e),
+            // so the softmax uses v_exp_f32 (exp2) directly.
             float mloc = -INFINITY;
+            if (key0 + 32 <= L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float v = key < L ? s[r] + bt[key - qic + (maxL - 1)] : -INFINITY;
-                s[r] = v;
-                mloc = fmaxf(mloc, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = s[r] + bt[key - qic + (maxL - 1)];
+                    s[r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = key < L ? s[r] + bt[key - qic + (maxL - 1)] : -INFINITY;
+                    s[r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
             const float mnew = fmaxf(mrun, mloc);  // finite: key0 < L means at least one valid key
-            const float alpha = __expf(mrun - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[r] - mnew);
+                const float p = __builtin_amdgcn_exp2f(s[r] - mnew);
                 s[r] = p;
                 lsum += p;
             }
             lrun = lrun * alpha + lsum;
             mrun = mnew;
+            if (!__all(alpha == 1.0f)) {  // the running max moves in the first tiles only
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+            }
             // O^T[d][query] += V^T[d][key] . P^T[key][query]
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -615,30 +630,54 @@ __global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- pooling
-// One block per sequence: e = sum_t y_t / max(len, 1e-9); optional e / max(||e||, 1e-12).
+// Masked mean pooling + optional L2 normalise, deterministic two-stage reduction:
+// k_pool_partial: grid (B, S) -- slice s of sequence b sums its share of the token rows into
+//                 part[b][s][H] (coalesced row reads, fixed summation order);
+// k_pool_final:   one block per sequence adds the S partial rows in order,
+//                 e = sum / max(len, 1e-9), optional e / max(||e||, 1e-12).
 template <int H>
-__global__ __launch_bounds__(256) void k_pool_norm(const float* __restrict__ y, const int32_t* __restrict__ cu,
-                                                   int normalize, float* __restrict__ out) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ y, const int32_t* __restrict__ cu,
+                                                      int S, float* __restrict__ part) {
+    const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
     const int t0 = cu[b], L = cu[b + 1] - t0;
+    const int per = (L + S - 1) / S;
+    const int lo = min(L, sl * per), hi = min(L, lo + per);
     constexpr int PER = (H + 255) / 256;
     float acc[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) acc[i] = 0.f;
-    for (int t = 0; t < L; ++t) {
+    for (int t = lo; t < hi; ++t) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int c = tid + 256 * i;
             if (c < H) acc[i] += y[(size_t)(t0 + t) * H + c];
         }
     }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        if (c < H) part[((size_t)b * S + sl) * H + c] = acc[i];
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void k_pool_final(const float* __restrict__ part, const int32_t* __restrict__ cu,
+                                                    int S, int normalize, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = cu[b + 1] - cu[b];
+    constexpr int PER = (H + 255) / 256;
+    float acc[PER];
     const float denom = fmaxf((float)L, 1e-9f);
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        acc[i] = acc[i] / denom;
-        if (tid + 256 * i < H) ss += acc[i] * acc[i];
+        const int c = tid + 256 * i;
+        float a = 0.f;
+        if (c < H)
+            for (int sl = 0; sl < S; ++sl) a += part[((size_t)b * S + sl) * H + c];
+        acc[i] = a / denom;
+        if (c < H) ss += acc[i] * acc[i];
     }
     ss = wave_allsum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;

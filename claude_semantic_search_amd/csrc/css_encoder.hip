@@ -261,6 +261,17 @@ int g_gemm_ring = 2;       // CSS_GEMM_RING: 2 = 2 stages x 128 B rows (default:
 template <typename TIn, int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                 float qscale, int num_cus, hipStream_t st, const char* prof) {
+    if (M <= 64 && N % 32 == 0 && K % 768 == 0) {  // single-query / tiny batches: weight-streaming kernel (K/4 = 12n fragment steps)
+        ProfScope ps(prof, st);
+        if (M <= 32)
+            hipLaunchKernelGGL((k_gemm_skinny<TIn, EPI, 1>), dim3(N / 32), dim3(256), 0, st, (const TIn*)A, (const TIn*)W,
+                               bias, C, M, N, K, qscale_cols, qscale);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<TIn, EPI, 2>), dim3(N / 32), dim3(256), 0, st, (const TIn*)A, (const TIn*)W,
+                               bias, C, M, N, K, qscale_cols, qscale);
+        CSS_LAUNCH_CHECK();
+        return CSS_OK;
+    }
     if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
         // ring shape: 4 x 64 KiB... (NST stages x RB bytes of K per row); CSS_GEMM_RING selects for A/B runs
         if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);

@@ -415,6 +415,90 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 #undef GM_ISSUE
 }
 
+// ---------------------------------------------------------------- skinny GEMM (M <= 64 tokens)
+// The single-query path (generate_single_embedding, src/embeddings.py:179-190) is a
+// weight-streaming problem: 85 MB of bf16 weights per forward, a few dozen tokens.  The big
+// persistent kernel would run 12..48 latency-bound K-stages on a handful of CUs; here every
+// block owns 32 output columns, its 4 waves split K four ways and stream their W slices
+// straight into MFMA fragments (no LDS, deep load queue), then reduce through LDS.
+// Same transposed product / epilogue semantics as k_gemm.
+template <typename TIn, int EPI, int MT>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const TIn* __restrict__ A, const TIn* __restrict__ W,
+                                                     const float* __restrict__ bias, void* __restrict__ Cout, int M,
+                                                     int N, int K, int qscale_cols, float qscale) {
+    constexpr bool BF = sizeof(TIn) == 2;
+    constexpr int KS = 16 / (int)sizeof(TIn) * 2;  // K elements per 16-B fragment pair step: 16 (bf16) / 8 (f32)
+    __shared__ float red[4][MT][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int col0 = blockIdx.x * 32;
+    const int kq = K / 4;  // this wave's K range
+    const char* wp = reinterpret_cast<const char*>(W + (size_t)(col0 + fr) * K + wave * kq) + fh * 16;
+    const char* ap[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int tok = 32 * m + fr;
+        tok = tok < M ? tok : M - 1;
+        ap[m] = reinterpret_cast<const char*>(A + (size_t)tok * K + wave * kq) + fh * 16;
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    // groups of 12 fragment steps are loaded back to back (12 x 16 B of W and of each token
+    // tile per lane in flight) before their MFMAs: the kernel lives on memory-level parallelism
+    constexpr int UNR = 12;
+    const int nsteps = kq / KS;  // multiple of 12 for K in {768, 3072} (host check)
+    for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+        v4f wf[UNR], af[MT][UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            wf[u] = *reinterpret_cast<const v4f*>(wp + (size_t)(s0 + u) * 32);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m][u] = *reinterpret_cast<const v4f*>(ap[m] + (size_t)(s0 + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (BF) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wf[u]),
+                                                                    __builtin_bit_cast(v8bf, af[m][u]), acc[m], 0, 0, 0);
+                } else {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u].x, af[m][u].x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u].y, af[m][u].y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u].z, af[m][u].z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u].w, af[m][u].w, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][m][r][lane] = acc[m][r];
+    __syncthreads();
+    // 256 threads finish MT*16*64 elements: element (m, r, l): column = col0 + (r&3)+8(r>>2)+4(l>>5), token = 32m+(l&31)
+    for (int e = tid; e < MT * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, m = e >> 10;
+        const int tok = 32 * m + (l & 31);
+        if (tok >= M) continue;
+        const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float v = ((red[0][m][r][l] + red[1][m][r][l]) + (red[2][m][r][l] + red[3][m][r][l])) + bias[col];
+        const size_t o = (size_t)tok * N + col;
+        if constexpr (EPI == EPI_RESID) {
+            reinterpret_cast<float*>(Cout)[o] = v;
+        } else {
+            if constexpr (EPI == EPI_GELU) v = BF ? gelu_erf_fast(v) : gelu_erf(v);
+            if constexpr (EPI == EPI_QKV) v *= col < qscale_cols ? qscale : 1.0f;
+            if constexpr (BF) reinterpret_cast<bf16_t*>(Cout)[o] = f2bf(v);
+            else reinterpret_cast<float*>(Cout)[o] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- attention (bf16, MFMA)
 // Block = (sequence, 128-query block, head), 4 waves x 32 queries.  Swapped
 // product S^T = K.Q^T keeps one query per lane (softmax in registers, one

@@ -40,6 +40,7 @@ struct DeviceGuard {
 };
 
 int check_device(int device);  // CSS_OK or CSS_ERR_NO_DEVICE / CSS_ERR_INVALID
+bool prof_enabled();
 
 }  // namespace css
 

@@ -55,6 +55,8 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::map<std::string, std::vector<ProfRec>> g_prof;
 
+bool prof_enabled() { return g_prof_on; }
+
 ProfScope::ProfScope(const char* name, hipStream_t stream) : name_(name), stream_(stream) {
     if (!g_prof_on) return;
     if (hipEventCreate(&start_) != hipSuccess) return;

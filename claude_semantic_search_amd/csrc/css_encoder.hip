@@ -95,6 +95,14 @@ struct css_encoder {
     void *x16 = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;  // operand-typed
     int32_t *ids_dev = nullptr, *cu_dev = nullptr;
     float* out_dev = nullptr;
+    // hipGraph cache for the launch-bound tiny-batch path (generate_single_embedding): key =
+    // (B, T, max_len, normalize); a key is run eagerly once, captured on its second use, replayed after
+    struct GraphEntry {
+        int uses = 0;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::map<uint64_t, GraphEntry> graphs;
+    bool graphs_ok = true;
     std::mutex mu;
 };
 
@@ -199,6 +207,11 @@ int ensure_acts(css_encoder* e, int T, int B) {
     const size_t H = c.hidden, F = c.ffn;
     const size_t es = c.compute == 0 ? 2 : 4;
     T = std::max(T, 8 * B);  // pre32 also holds the [B][8][H] pooling partials
+    if (T > e->cap_tokens || B > e->cap_seqs) {
+        for (auto& kv : e->graphs)
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        e->graphs.clear();  // captured pointers are about to change
+    }
     if (T > e->cap_tokens) {
         void* ptrs[] = {e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev};
         for (void* p : ptrs)
@@ -406,6 +419,8 @@ int css_encoder_free(css_encoder* e) {
     if (!e) return CSS_OK;
     DeviceGuard g(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     for (auto& kv : e->params) {
         // q/k/v views alias the fused tensors: free only owning entries
         const std::string& n = kv.first;
@@ -533,7 +548,38 @@ int css_encoder_forward(css_encoder* e, const int32_t* ids, const int32_t* cu, i
     if (rc != CSS_OK) return rc;
     CSS_HIP_TRY(hipMemcpyAsync(e->ids_dev, ids, (size_t)T * 4, hipMemcpyHostToDevice, e->stream));
     CSS_HIP_TRY(hipMemcpyAsync(e->cu_dev, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, e->stream));
-    if ((rc = forward_any(e, e->ids_dev, e->cu_dev, B, T, max_len, normalize, e->out_dev, e->stream)) != CSS_OK) return rc;
+    bool done = false;
+    if (e->graphs_ok && T <= 64 && B <= 8 && !css::prof_enabled()) {
+        // ~90 launches of a few microseconds each: replay them as one hipGraph
+        const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)T << 20) | ((uint64_t)max_len << 1) | (normalize ? 1u : 0u);
+        auto& ge = e->graphs[key];
+        ++ge.uses;
+        if (ge.exec == nullptr && ge.uses == 2) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int frc = forward_any(e, e->ids_dev, e->cu_dev, B, T, max_len, normalize, e->out_dev, e->stream);
+                const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+                if (frc == CSS_OK && ce == hipSuccess && graph &&
+                    hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    // instantiated
+                } else {
+                    ge.exec = nullptr;
+                    e->graphs_ok = false;  // fall back to eager launches for good
+                    (void)hipGetLastError();
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            } else {
+                e->graphs_ok = false;
+                (void)hipGetLastError();
+            }
+        }
+        if (ge.exec) {
+            CSS_HIP_TRY(hipGraphLaunch(ge.exec, e->stream));
+            done = true;
+        }
+    }
+    if (!done && (rc = forward_any(e, e->ids_dev, e->cu_dev, B, T, max_len, normalize, e->out_dev, e->stream)) != CSS_OK)
+        return rc;
     CSS_HIP_TRY(hipMemcpyAsync(out, e->out_dev, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, e->stream));
     CSS_HIP_TRY(hipStreamSynchronize(e->stream));
     return CSS_OK;

@@ -177,6 +177,38 @@ def bench_encoder(args, dev, log):
                                "sample": f"{nb} of the {B} sequences (L={L}) through oracle.mpnet_oracle (torch fp32)"}
         res["parity_vs_oracle_min_cos"] = float(cos.min())
         log(f"encoder cpu baseline: {nb} seqs in {tc:.2f}s; min cos vs oracle {cos.min():.6f}")
+    # second shape: the chunk-length mix of config 1 (chars ~ U[100, 2000],
+    # tokens = clip(round(chars / 4) + 2, 2, 384)), packed var-len, same batch size
+    chars = 100 + synth.uint(11, np.arange(B, dtype=np.uint64), 0, 1901)
+    lens = np.clip(np.round(chars / 4.0).astype(np.int64) + 2, 2, 384)
+    lens = np.sort(lens)[::-1].copy()  # sentence-transformers batches are length sorted
+    Tm = int(lens.sum())
+    cu_m = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu_m[1:])
+    ids_m = synth.uint(13, np.arange(Tm, dtype=np.uint64), 4, enc.cfg["vocab"]).astype(np.int32)
+    ids_m[cu_m[:-1]] = 0
+    ids_m[cu_m[1:] - 1] = 2
+    ids2 = torch.from_numpy(ids_m).to(dev)
+    cu2 = torch.from_numpy(cu_m).to(dev)
+
+    def fwd2():
+        nat.check(nat.lib().css_encoder_forward_dev(enc._h, ctypes.c_void_p(ids2.data_ptr()), ctypes.c_void_p(cu2.data_ptr()),
+                                                    B, Tm, int(lens.max()), 1, ctypes.c_void_p(out.data_ptr()),
+                                                    ctypes.c_void_p(stream)))
+
+    for _ in range(2):
+        fwd2()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.enc_steps):
+        fwd2()
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / args.enc_steps
+    fl2 = encoder_flops(lens.tolist())
+    res["length_mix"] = {"chunks_per_s": B / dt2, "ms_per_batch": dt2 * 1e3, "mean_tokens": float(lens.mean()),
+                         "total_tokens": Tm, "achieved_TFLOPs": fl2 / dt2 / 1e12,
+                         "frac_of_bf16_peak": fl2 / dt2 / 1e12 / BF16_MFMA_PEAK_TF}
+    log(f"encoder length mix: mean {lens.mean():.0f} tokens -> {B / dt2:.0f} chunks/s, {fl2 / dt2 / 1e12:.0f} TFLOP/s")
     enc.close()
     return res
 

@@ -244,13 +244,13 @@ extern int g_gemm_dbg;
 extern int g_gemm_ring;
 // Tile shapes: 2x2 waves x (2x2) MFMA tiles = 128x128, or 2x4 waves x (4x2) tiles = 256x256
 // (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
-template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB, int SPS>
 int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   float qscale, int num_cus, hipStream_t st, const char* prof) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     CSS_REQUIRE(N % BN == 0 && K % 64 == 0 && K / 64 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
-    auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB>;
+    auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB, SPS>;
     const size_t lds = (size_t)NST * (BM + BN) * RB;  // ring of NST stages, RB bytes of K per row
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -287,11 +287,12 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M,
     }
     if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
         // ring shape: 4 x 64 KiB... (NST stages x RB bytes of K per row); CSS_GEMM_RING selects for A/B runs
-        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
-        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
-        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        if (g_gemm_ring == 5) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 5, 64, 2>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
     }
-    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+    return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
 }
 
 template <typename TIn>

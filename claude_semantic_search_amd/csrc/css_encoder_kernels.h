@@ -198,7 +198,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // PPW LDS-DMA instructions per stage and E unconditional stores per tile (rows beyond M land
 // in the slack rows every activation buffer has).
 // dbg: timing experiments only (bit0 skip epilogue, bit1 skip MFMA, bit2 skip loads).
-template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB>
+template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB, int SPS>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A, const TIn* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ Cout, int M,
                                                       int N, int K, int qscale_cols, float qscale, int dbg) {
@@ -214,8 +214,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
     constexpr int PPW = PIECES / NW;        // LDS-DMA instructions per wave per stage
     constexpr int E = TM * TN * 4;          // store instructions per wave per tile
-    static_assert((NST - 2) * PPW + E <= 63, "vmcnt is a 6-bit counter");
-    static_assert(NST >= 2 && NST <= 4, "ring depth");
+    // SPS ring stages are consumed per barrier step; Y stages stay in flight across a step's wait
+    constexpr int Y = NST - 2 * SPS;
+    static_assert(Y >= 0 && Y <= 2 && (SPS == 1 || SPS == 2), "ring shape");
+    static_assert(Y * PPW + E <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST][A_BYTES | B_BYTES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,10 +276,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 #pragma unroll
             for (int r2 = 0; r2 < 16; ++r2) acc[m][n][r2] = 0.f;
 
-    // issue side runs NST-1 stages ahead of the compute side
+    // issue side runs NST-SPS stages ahead of the compute side
     int it_tile = 0, it_kt = 0, gi = 0;  // gi: global stage index of the next stage to issue
     set_src(0);
-    for (int p = 0; p < NST - 1 && gi < total; ++p) {
+    for (int p = 0; p < NST - SPS && gi < total; ++p) {
         if (!(dbg & 4)) {
             GM_ISSUE(it_kt, gi % NST)
         }
@@ -288,31 +290,36 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
         }
     }
     int ct_tile = 0, kt = 0;
-    for (int g = 0; g < total; ++g) {
-        // stage g has landed once only the younger operations are outstanding
-        const int younger = min(NST - 2, total - 1 - g);  // stages issued after stage g and still allowed in flight
-        const bool stores_younger = ct_tile > 0 && kt < NST - 1;  // this tile's first stages were issued before the previous epilogue
+    for (int g = 0; g < total; g += SPS) {  // total and KT are multiples of SPS (host check)
+        // stages g .. g+SPS-1 have landed once only the younger operations are outstanding
+        const int younger = min(Y, total - 1 - (g + SPS - 1));  // stages issued after them, allowed in flight
+        // this tile's first NST-SPS stages were issued before the previous tile's epilogue stores
+        const bool stores_younger = ct_tile > 0 && (kt + SPS - 1) < NST - SPS;
         if (dbg & 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (stores_younger) {
-            // (KT >= NST - 1, host check: NST-2 younger stages exist here)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW + E) : "memory");
-        } else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 4 ? 2 : 0) * PPW) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 3 ? 1 : 0) * PPW) : "memory");
+            // (KT >= NST: the Y younger stages exist here)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * PPW + E) : "memory");
+        } else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Y >= 2 ? 2 : 0) * PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Y >= 1 ? 1 : 0) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // all pieces of stage g landed; the slot of stage g-1 is free
-        if (gi < total) {
-            if (!(dbg & 4)) {
-                GM_ISSUE(it_kt, gi % NST)
+        __builtin_amdgcn_s_barrier();  // all pieces of this step's stages landed; the previous step's slots are free
+#pragma unroll
+        for (int u = 0; u < SPS; ++u)
+            if (gi < total) {
+                if (!(dbg & 4)) {
+                    GM_ISSUE(it_kt, gi % NST)
+                }
+                ++gi;
+                if (++it_kt == KT) {
+                    it_kt = 0;
+                    if (++it_tile < my_ntiles) set_src(it_tile);
+                }
             }
-            ++gi;
-            if (++it_kt == KT) {
-                it_kt = 0;
-                if (++it_tile < my_ntiles) set_src(it_tile);
-            }
-        }
-        const char* Ab = smem + (g % NST) * STAGE;
-        const char* Bb = Ab + A_BYTES;
         if (!(dbg & 2))
+#pragma unroll
+        for (int u = 0; u < SPS; ++u) {
+        const char* Ab = smem + ((g + u) % NST) * STAGE;
+        const char* Bb = Ab + A_BYTES;
 #pragma unroll
         for (int c = 0; c < CPR / 2; ++c) {
             v4f a[TM], b[TN];
@@ -342,7 +349,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
                     }
                 }
         }
-        if (++kt == KT) {
+        }
+        kt += SPS;
+        if (kt == KT) {
             // ---- epilogue of tile ct_tile: bias (LDS) + activation + E unconditional stores.
             // lane = token row (fr of the 32-row tile); register group g4 = the 4 consecutive
             // output columns 8*g4 + 4*fh + {0..3} of each 32-column tile.

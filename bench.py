@@ -237,6 +237,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+    # CSS_BENCH_ONE_GPU=1 (rehearsal of the N > 1 path on a one-GPU box): every rank uses cuda:0 over gloo
+    one_gpu = os.environ.get("CSS_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.only_encoder:
@@ -244,7 +248,10 @@ def main():
         return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- build this rank's shard in HBM (rows generated on the device) -------
     lo = rank * args.rows // world
@@ -273,8 +280,16 @@ def main():
     def step():
         index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
         if world > 1:
-            dist.all_gather_into_tensor(Dg.view(world * args.nq, args.k), D)
-            dist.all_gather_into_tensor(Ig.view(world * args.nq, args.k), I)
+            if one_gpu:  # gloo has no device all_gather_into_tensor: stage through the host (rehearsal only)
+                dl = [torch.empty_like(D, device="cpu") for _ in range(world)]
+                il = [torch.empty_like(I, device="cpu") for _ in range(world)]
+                dist.all_gather(dl, D.cpu())
+                dist.all_gather(il, I.cpu())
+                Dg.copy_(torch.stack(dl))
+                Ig.copy_(torch.stack(il))
+            else:
+                dist.all_gather_into_tensor(Dg.view(world * args.nq, args.k), D)
+                dist.all_gather_into_tensor(Ig.view(world * args.nq, args.k), I)
             nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dg.data_ptr()), ctypes.c_void_p(Ig.data_ptr()),
                                                    world, args.nq, args.k, 0, ctypes.c_void_p(Dm.data_ptr()),
                                                    ctypes.c_void_p(Im.data_ptr()), local_rank,
@@ -297,7 +312,7 @@ def main():
     elapsed = time.perf_counter() - t0
     nat.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -369,7 +384,7 @@ def main():
             # encoder: replicas only (weights replicated, one batch per rank, no collective in the path)
             args.no_cpu_baseline = True
             enc = bench_encoder(args, dev, (lambda m: None) if rank else log)
-            t = torch.tensor([enc["chunks_per_s"], enc["ms_per_batch"]], dtype=torch.float64, device=dev)
+            t = torch.tensor([enc["chunks_per_s"], enc["ms_per_batch"]], dtype=torch.float64, device="cpu" if one_gpu else dev)
             tsum = t.clone()
             dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

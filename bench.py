@@ -97,6 +97,24 @@ def encoder_flops(lengths, layers=12):
     return float(sum(layers * (L * 14155776 + 4 * L * L * 768) for L in lengths))
 
 
+def pmc_traffic(kernel_prefix, workload):
+    """HBM bytes per launch of `kernel_prefix` from the newest committed rocprofv3 PMC summary
+    (profiles/r*_pmc_hbm_traffic.json, made by tools/pmc_summarise.py from separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE passes over this same command); None when no summary matches this workload."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix):
+                return {"bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def bench_encoder(args, dev, log):
     """Batch-256 x 384-token encode (BASELINE.json configs[2]): synthetic ids + seeded weights."""
     import ctypes
@@ -347,6 +365,13 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": sweep_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": sweep_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "launches": n, "avg_ms": ms / n}
+    if roofline:
+        wl = {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k}
+        tr = pmc_traffic("k_scan_mfma" if dom == "knn_scan_mfma" else "k_scan_small", wl)
+        if tr:
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
+            roofline["algorithmic_bytes_per_launch"] = sweep_bytes
     nat.prof_reset()
 
     # ---- extra: the reference's real call shape (one query, k'=100) -------------
@@ -369,8 +394,12 @@ def main():
             nat.prof_enable(False)
             ms, n = nat.prof_read("knn_scan_small")
             gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
+            tr = pmc_traffic("k_scan_small<1,", {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
             extra[f"nq1_k{kq}"] = {"latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
-                                   "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS if gbs else None}
+                                   "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                                                "traffic": tr["bytes_per_launch"] if tr else None,
+                                                "algorithmic_bytes_per_launch": shard * args.dim * 4}}
             nat.prof_reset()
 
     cpu = None

@@ -41,6 +41,9 @@ struct css_index {
     int64_t ntotal = 0, cap = 0, id_base = 0;
     float* xb = nullptr;
     float* xnorm2 = nullptr;
+    unsigned short* xh = nullptr;  // bf16 shadow rows [cap][dpad] for the coarse scan (nullptr: not kept)
+    int shadow = -1;               // -1 undecided, 0 off, 1 on (CSS_KNN_SHADOW, HBM headroom)
+    int* maxn2 = nullptr;          // device scalar: bits of max ||row||^2 (coarse error bound)
     hipStream_t stream = nullptr;
     int num_cus = 256;
     // reusable workspaces (grown on demand, guarded by ws_mu)
@@ -52,6 +55,13 @@ struct css_index {
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
     float* out_d = nullptr;   int64_t* out_i = nullptr; size_t out_cap = 0;     // entries
     float* stage = nullptr;   size_t stage_cap = 0;     // floats
+    // coarse + rescore path (css_knn_coarse.h)
+    unsigned short* qh = nullptr; size_t qh_cap = 0;    // bf16 queries
+    float* cthr = nullptr;    size_t cthr_cap = 0;
+    int* cand_n = nullptr;    size_t cand_n_cap = 0;
+    int* cflags = nullptr;    size_t cflags_cap = 0;    // [nq_pad] flags | [nq_pad] flagged list | [1] count
+    float* cand_s = nullptr;  size_t cand_s_cap = 0;
+    uint32_t* cand_i = nullptr; size_t cand_i_cap = 0;
     std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
     std::mutex ws_mu;      // workspaces + own stream are single-user
 };
@@ -78,7 +88,8 @@ int grow(T** p, size_t* cap, size_t need) {
 template <bool SYNTH>
 __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ src, float* __restrict__ dst,
                                                      float* __restrict__ norm2, int64_t n, int dim, int dpad,
-                                                     int normalize, uint64_t seed, int64_t first_row) {
+                                                     int normalize, uint64_t seed, int64_t first_row,
+                                                     unsigned short* __restrict__ dsth, int* __restrict__ maxn2) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -101,10 +112,15 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
             if (normalize) v = v / nrm;
         }
         d[c] = v;
+        if (dsth) dsth[row * (int64_t)dpad + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
         s2 = fmaf(v, v, s2);
     }
     s2 = wave_allsum(s2);
     if (lane == 0 && norm2) norm2[row] = s2;
+    // running max of ||row||^2 (non-negative floats order like their bit patterns); rows are ~unit
+    // norm in the product, so after the first few rows almost no atomic is issued
+    if (lane == 0 && maxn2 && s2 > __int_as_float(__hip_atomic_load(maxn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        atomicMax(maxn2, __float_as_int(s2));
 }
 
 // ------------------------------------------------------------------ scan (small nq)
@@ -480,6 +496,9 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
 // NW waves x 32 queries = BN query columns per block; every wave holds MT 32-row tiles (BM = 32*MT rows).
 // (NW, MT) = (4, 4): 128x128 tile, <= 80 KiB LDS, two blocks per CU; (8, 8): 256x256 tile, one block of
 // 8 waves per CU, half the operand bytes per MFMA (the CU's L2->LDS path is the scarce resource).
+// The l_x.l_q product is <= 2^-18 |x.q| per term -- the size of the split's own truncation error -- and is
+// not formed (three MFMAs per fp32-grade product instead of four).
+constexpr bool kSplitLowLow = false;
 template <int METRIC, int NW, int MT>
 __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __restrict__ xb, const float* __restrict__ xnorm2,
                                                       const unsigned short* __restrict__ qsplit, int nq_real, int64_t ntotal,
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
                     al_n = *reinterpret_cast<const v8bf*>(A + mf_swz(32 * (m + 1) + fr, 4 + 2 * ks + fh));
                 }
                 // (h_x + l_x).(h_q + l_q): small terms first
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[m], 0, 0, 0);
+                if constexpr (kSplitLowLow) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
@@ -773,6 +792,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
 }
 
 
+
+#include "css_knn_coarse.h"
 
 // qpad [nq_pad][dpad] fp32 -> qsplit [nq_pad][dpad/32][h(32) | l(32)] bf16
 __global__ void k_split_queries(const float* __restrict__ qpad, unsigned short* __restrict__ qsplit, int64_t n, int dpad) {
@@ -963,12 +984,24 @@ __global__ void k_fill_int(int* p, int n, int v) {
 }
 
 // ---------------------------------------------------------------- host side
-int ensure_capacity(css_index* ix, int64_t need) {
-    if (need <= ix->cap) return CSS_OK;
-    int64_t ncap = std::max<int64_t>(need, ix->cap + ix->cap / 2);
-    ncap = std::max<int64_t>(ncap, 1024);
+// bf16 shadow rows for the coarse scan: kept when the metric is inner product, rows are a whole number
+// of 64-element K stages and fp32 + bf16 rows fit in 80 % of the HBM (CSS_KNN_SHADOW=0/1 overrides).
+bool want_shadow(css_index* ix, int64_t ncap) {
+    if (ix->shadow == 0) return false;
+    if (ix->metric != CSS_METRIC_IP || ix->dpad % 64 != 0) return false;
+    const char* e = getenv("CSS_KNN_SHADOW");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    return (double)ncap * ix->dpad * 6.0 <= 0.8 * (double)tot;
+}
+
+// (Re)allocate the row storage for exactly ncap rows, carrying the ntotal existing rows over.
+int reallocate_rows(css_index* ix, int64_t ncap) {
     float* nxb = nullptr;
     float* nn2 = nullptr;
+    unsigned short* nxh = nullptr;
     hipError_t e = hipMalloc((void**)&nxb, (size_t)ncap * ix->dpad * sizeof(float));
     if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(index rows)", __FILE__, __LINE__);
     e = hipMalloc((void**)&nn2, (size_t)ncap * sizeof(float));
@@ -976,18 +1009,48 @@ int ensure_capacity(css_index* ix, int64_t need) {
         (void)hipFree(nxb);
         return css::hip_fail(e, "hipMalloc(index norms)", __FILE__, __LINE__);
     }
+    // the shadow can only be carried over (or started on an empty index), never rebuilt here
+    const bool can_shadow = ix->xh != nullptr || ix->ntotal == 0;
+    if (can_shadow && want_shadow(ix, ncap)) {
+        if (hipMalloc((void**)&nxh, (size_t)ncap * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
+            (void)hipGetLastError();  // no room: batched search falls back to the split-operand kernel
+            nxh = nullptr;
+        }
+    }
     if (ix->ntotal > 0) {
         CSS_HIP_TRY(hipMemcpyAsync(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float),
                                    hipMemcpyDeviceToDevice, ix->stream));
         CSS_HIP_TRY(hipMemcpyAsync(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
                                    ix->stream));
+        if (nxh)
+            CSS_HIP_TRY(hipMemcpyAsync(nxh, ix->xh, (size_t)ix->ntotal * ix->dpad * sizeof(unsigned short),
+                                       hipMemcpyDeviceToDevice, ix->stream));
         CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     }
     if (ix->xb) CSS_HIP_TRY(hipFree(ix->xb));
     if (ix->xnorm2) CSS_HIP_TRY(hipFree(ix->xnorm2));
+    if (ix->xh) CSS_HIP_TRY(hipFree(ix->xh));
     ix->xb = nxb;
     ix->xnorm2 = nn2;
+    ix->xh = nxh;
+    ix->shadow = nxh ? 1 : 0;
     ix->cap = ncap;
+    return CSS_OK;
+}
+
+int ensure_capacity(css_index* ix, int64_t need) {
+    if (need > ix->cap) {
+        int64_t ncap = std::max<int64_t>(need, ix->cap + ix->cap / 2);
+        return reallocate_rows(ix, std::max<int64_t>(ncap, 1024));
+    }
+    if (ix->ntotal == 0 && !ix->xh && ix->shadow < 0 && ix->cap > 0 && want_shadow(ix, ix->cap)) {
+        // emptied index (css_index_reset): start a shadow again if there is room now
+        if (hipMalloc((void**)&ix->xh, (size_t)ix->cap * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
+            (void)hipGetLastError();
+            ix->xh = nullptr;
+        }
+        ix->shadow = ix->xh ? 1 : 0;
+    }
     return CSS_OK;
 }
 
@@ -997,12 +1060,13 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
     CSS_REQUIRE(blocks < (1ll << 31), "ingest: too many rows in one call");
     float* dst = ix->xb + (size_t)ix->ntotal * ix->dpad;
     float* n2 = ix->xnorm2 + ix->ntotal;
+    unsigned short* dh = ix->xh ? ix->xh + (size_t)ix->ntotal * ix->dpad : nullptr;
     if (synth)
         hipLaunchKernelGGL(k_ingest_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, nullptr, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, seed, first_row);
+                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2);
     else
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x_dev, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, 0ull, 0ll);
+                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1086,8 +1150,10 @@ int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb
 }
 
 
-// Query batches: split-bf16 MFMA (default) or exact fp32 MFMA (CSS_KNN_BATCH=fp32, verification).
+// Query batches: coarse bf16 scan + exact rescoring (default when the index keeps bf16 shadow rows),
+// split-bf16 MFMA (CSS_KNN_BATCH=split, and the fallback) or exact fp32 MFMA (CSS_KNN_BATCH=fp32, verification).
 int g_knn_batch_split = -1;
+int g_knn_batch_coarse = -1;
 
 template <int METRIC>
 int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
@@ -1154,6 +1220,95 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
     return CSS_OK;
 }
 
+// Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [0, nq) of ix->qpad; nq <= 4096.
+// Returns the number of flagged queries (their ids in `flagged`) whose result must be recomputed on the exact path.
+int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st,
+                       std::vector<int>* flagged) {
+    const float* qpad = ix->qpad + (size_t)q0 * ix->dpad;
+    const float* qnorm2 = ix->qnorm2 + q0;
+    D_dev += (size_t)q0 * k;
+    I_dev += (size_t)q0 * k;
+    const int nq_pad = (nq + CZ_T - 1) / CZ_T * CZ_T;
+    const int nqt = nq_pad / CZ_T;
+    int rc;
+    if ((rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cthr, &ix->cthr_cap, (size_t)nq_pad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, (size_t)nq_pad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cflags, &ix->cflags_cap, (size_t)2 * nq_pad + 1)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, (size_t)nq_pad * CZ_CAP)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, (size_t)nq_pad * CZ_CAP)) != CSS_OK) return rc;
+    int* flags = ix->cflags;
+    int* flag_list = ix->cflags + nq_pad;
+    int* nflag = ix->cflags + 2 * nq_pad;
+
+    // cascade schedule: stage 0 reads every s0-th row tile (2..7 tiles), then strides s0/4 ... 1
+    const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
+    int64_t s0 = 1;
+    while (ntiles / (s0 * 4) >= 2) s0 *= 4;
+    const int64_t n0 = (ntiles + s0 - 1) / s0;
+
+    {
+        const int64_t ne = (int64_t)nq_pad * ix->dpad;
+        hipLaunchKernelGGL(k_rows_to_bf16, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qh,
+                           (int64_t)nq, (int64_t)nq_pad, ix->dpad);
+        CSS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
+                           nflag, nq, nq_pad, (int)(n0 * CZ_T));
+        CSS_LAUNCH_CHECK();
+    }
+    const size_t lds = (size_t)CZ_NST * CZ_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = std::max(8, ix->num_cus / 8 * 8);
+    ProfScope all("knn_coarse_cascade", st);
+    for (int64_t s = s0;; s /= 4) {
+        const bool stage0 = s == s0;
+        const int64_t W = (ntiles + s - 1) / s;
+        const int64_t count = stage0 ? W : (W - 1) - (W - 1) / 4;
+        if (count > 0) {
+            if (stage0) {
+                hipLaunchKernelGGL((k_scan_coarse<true, false>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
+                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
+            } else if (s == 1) {
+                ProfScope ps("knn_scan_coarse_main", st);
+                hipLaunchKernelGGL((k_scan_coarse<false, true>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
+                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
+            } else {
+                hipLaunchKernelGGL((k_scan_coarse<false, false>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
+                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
+            }
+            CSS_LAUNCH_CHECK();
+        }
+        if (s == 1) {
+            hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
+                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, k, qpad, ix->xb, ix->dpad,
+                               ix->id_base, D_dev, I_dev);
+            CSS_LAUNCH_CHECK();
+            break;
+        }
+        hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
+                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, k, qpad, ix->xb, ix->dpad,
+                           ix->id_base, D_dev, I_dev);
+        CSS_LAUNCH_CHECK();
+    }
+    // one host round trip per batch: which queries overflowed their candidate buffer or band?
+    int h_nflag = 0;
+    CSS_HIP_TRY(hipMemcpyAsync(&h_nflag, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    CSS_HIP_TRY(hipStreamSynchronize(st));
+    if (h_nflag > 0) {
+        std::vector<int> f((size_t)h_nflag);
+        CSS_HIP_TRY(hipMemcpyAsync(f.data(), flag_list, (size_t)h_nflag * sizeof(int), hipMemcpyDeviceToHost, st));
+        CSS_HIP_TRY(hipStreamSynchronize(st));
+        for (int v : f) flagged->push_back(q0 + v);
+    }
+    return CSS_OK;
+}
+
 // largest k the MFMA kernel's LDS lists hold next to its staging buffers
 constexpr int kMfmaMaxK = 64;
 
@@ -1171,7 +1326,8 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     {
         const int64_t blocks = (nq + 3) / 4;
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, q_dev, ix->qpad,
-                           ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll);
+                           ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll, (unsigned short*)nullptr,
+                           (int*)nullptr);
         CSS_LAUNCH_CHECK();
     }
     if (ix->ntotal == 0) {
@@ -1183,11 +1339,7 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         CSS_HIP_TRY(hipStreamSynchronize(st));
         return CSS_OK;
     }
-    if (nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0) {
-        return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
-                                           : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
-    }
-    // queries per sweep: keep the block's LDS (queries + lists) <= 64 KiB so >= 2 blocks fit a CU
+    // sweep geometry of the small-batch kernel (also the per-query fallback of the coarse path)
     int nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 4));
     CSS_REQUIRE(nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
     // enough blocks to fill the chip (8 per CU) but at least ~64 row groups of work each
@@ -1195,6 +1347,28 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ix->num_cus * 8, (ngroups + 63) / 64));
     const int64_t gpb = (ngroups + G - 1) / G;
     G = (ngroups + gpb - 1) / gpb;
+    if (g_knn_batch_coarse < 0) {
+        const char* m = getenv("CSS_KNN_BATCH");
+        g_knn_batch_coarse = (m && (std::string(m) == "fp32" || std::string(m) == "split")) ? 0 : 1;
+    }
+    if (g_knn_batch_coarse && nq > 16 && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
+        std::vector<int> flagged;
+        for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
+            const int nqc = (int)std::min<int64_t>(4096, nq - q0);
+            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, &flagged)) != CSS_OK) return rc;
+        }
+        if (flagged.empty()) return CSS_OK;
+        // candidate buffer / band overflow (e.g. thousands of duplicate rows): exact path for those queries
+        if (flagged.size() > 32 && k <= kMfmaMaxK) return launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st);
+        if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
+        for (int q : flagged)
+            if ((rc = search_chunk_small(ix, q, 1, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;
+        return CSS_OK;
+    }
+    if (nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0) {
+        return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
+                                           : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
+    }
     if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += nq_sweep) {
         const int nqc = (int)std::min<int64_t>(nq_sweep, nq - q0);
@@ -1226,6 +1400,13 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
         delete ix;
         return css::hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
     }
+    e = hipMalloc((void**)&ix->maxn2, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, sizeof(int));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ix->stream);
+        delete ix;
+        return css::hip_fail(e, "hipMalloc(maxn2)", __FILE__, __LINE__);
+    }
     *out = ix;
     return CSS_OK;
 }
@@ -1234,8 +1415,9 @@ int css_index_free(css_index* ix) {
     if (!ix) return CSS_OK;
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->xb, ix->xnorm2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
-                    ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage};
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
+                    ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
+                    ix->cflags, ix->cand_s, ix->cand_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     (void)hipStreamDestroy(ix->stream);
@@ -1247,6 +1429,10 @@ int css_index_reset(css_index* ix) {
     CSS_REQUIRE(ix, "css_index_reset: NULL index");
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     ix->ntotal = 0;
+    if (!ix->xh) ix->shadow = -1;
+    DeviceGuard g(ix->device);
+    CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, sizeof(int), ix->stream));
+    CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
 }
 
@@ -1256,25 +1442,7 @@ int css_index_reserve(css_index* ix, int64_t n) {
     DeviceGuard g(ix->device);
     if (n <= ix->cap) return CSS_OK;
     // exact-size allocation (no 1.5x growth): a 245 GB shard must not over-allocate
-    float* nxb = nullptr;
-    float* nn2 = nullptr;
-    hipError_t e = hipMalloc((void**)&nxb, (size_t)n * ix->dpad * sizeof(float));
-    if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(index rows)", __FILE__, __LINE__);
-    e = hipMalloc((void**)&nn2, (size_t)n * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(nxb);
-        return css::hip_fail(e, "hipMalloc(index norms)", __FILE__, __LINE__);
-    }
-    if (ix->ntotal > 0) {
-        CSS_HIP_TRY(hipMemcpy(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float), hipMemcpyDeviceToDevice));
-        CSS_HIP_TRY(hipMemcpy(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
-    }
-    if (ix->xb) CSS_HIP_TRY(hipFree(ix->xb));
-    if (ix->xnorm2) CSS_HIP_TRY(hipFree(ix->xnorm2));
-    ix->xb = nxb;
-    ix->xnorm2 = nn2;
-    ix->cap = n;
-    return CSS_OK;
+    return reallocate_rows(ix, n);
 }
 
 int css_index_ntotal(const css_index* ix, int64_t* n) {

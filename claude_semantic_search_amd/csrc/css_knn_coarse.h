@@ -1,0 +1,336 @@
+// css_knn_coarse.h -- batched exact search as "coarse bf16 scan + exact fp32 rescoring".
+// Included by css_index.hip (inside its anonymous namespace, after the MFMA vector types).
+//
+// Batched flat search (src/storage.py:424-436 with many queries) is a [rows x 768] . [768 x nq] product
+// followed by a top-k.  Computing every product to fp32 grade costs 3 bf16 MFMAs (split operands) and is
+// MFMA bound; but only ~k of the 10^7 scores per query matter.  So:
+//
+//   coarse   c(x, q) = bf16(x) . bf16(q), fp32 accumulate, ONE v_mfma_f32_32x32x16_bf16 per 32x32x16 block,
+//            from a bf16 shadow copy of the index rows (xh, +50 % HBM, kept next to the fp32 rows).
+//            Round-to-nearest bf16 has relative error <= 2^-8 per operand, so for every row
+//                |c(x,q) - x.q|  <=  eps_q = (2^-7 + 2^-11) ||q|| max_row ||x||      (Cauchy-Schwarz;
+//            the 2^-11 covers the fp32 accumulation of either side).
+//   select   Let Tc be the k-th largest coarse score of a query.  Every row of the exact top-k has
+//            c >= Tc - 2 eps_q  (the k rows with the largest c have exact scores >= Tc - eps, so the exact
+//            k-th best is >= Tc - eps, and a row that good has c >= Tc - 2 eps).  The candidate band
+//            {c >= Tc - 2 eps} holds k + a few dozen rows.
+//   rescore  exact fp32 dot products of the band rows against the fp32 index, sorted by (score desc, id asc).
+//
+// Finding the band without sorted lists in the hot kernel: the scan runs as a cascade over a nested,
+// uniformly strided sample of row tiles (stage 0: every s0-th tile, then strides s0/4, s0/16, ... 1, each
+// stage only the tiles not seen before).  Before each stage the k-th best coarse score of everything seen
+// so far gives a valid lower bound of the final Tc, so the stage appends only rows with c >= thr = Tc' - 2 eps
+// to a per-query candidate buffer (lane-local atomicAdd + two stores; ~3k + band rows per stage).  The hot
+// kernel is then a plain persistent bf16 GEMM (the encoder's LDS-DMA ring) whose epilogue is 128 compares.
+// A query whose buffer or band overflows is flagged and re-run on the exact path by the host.
+#pragma once
+
+constexpr int CZ_T = 256;            // rows per tile and queries per tile
+constexpr int CZ_RB = 128;           // bytes of K per LDS stage row (64 bf16)
+constexpr int CZ_STAGE = 2 * CZ_T * CZ_RB;   // 64 KiB: [256 query rows | 256 index rows] x 128 B
+constexpr int CZ_NST = 2;            // ring stages (measured fastest for the encoder GEMM: fewest barriers)
+constexpr int CZ_CAP = 4096;         // candidate slots per query
+constexpr int CZ_RMAX = 1024;        // largest band that is rescored in place (beyond: exact fallback)
+
+__device__ __forceinline__ int cz_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// fp32 rows -> bf16 rows (queries; rows >= n_real are zero filled)
+__global__ void k_rows_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n_real,
+                               int64_t n_pad, int dpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad * dpad) return;
+    const float x = i < n_real * dpad ? in[i] : 0.f;
+    out[i] = __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+
+// thr = -inf (real queries) / +inf (padding), counters and flags cleared
+__global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, int nq, int nq_pad, int n0rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *nflag = 0;
+    if (i >= nq_pad) return;
+    thr[i] = i < nq ? -INFINITY : INFINITY;
+    cand_n[i] = i < nq ? n0rows : 0;   // stage 0 writes its rows to fixed slots
+    flags[i] = 0;
+}
+
+// One stage of the cascade.  Grid = one block of 8 waves per CU (persistent).  Block -> (query tile, stream of
+// row tiles): the nqt blocks that share a row tile sit on one XCD (blockIdx % 8) and walk side by side, so the
+// tile's rows are fetched from HBM once per XCD L2.
+// Wave grid 2 (query halves) x 4 (row quarters); a wave holds 4 x 2 accumulator tiles of 32x32: lane = one
+// query column per 32-query tile (4 queries per lane), 32 registers of 64 index rows each.
+// STAGE0: every score is written to slot (tile ordinal * 256 + row in tile); otherwise scores >= thr are
+// appended.  MAIN only gives the last (stride 1, 3/4 of the rows) stage its own name in profiles.
+template <bool STAGE0, bool MAIN>
+__global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __restrict__ xh,
+                                                     const unsigned short* __restrict__ qh,
+                                                     const float* __restrict__ thr, float* __restrict__ cand_s,
+                                                     uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
+                                                     int64_t ntotal, int K, int nqt, int64_t count, int64_t stride) {
+    constexpr int NW = 8, WN = 4, TM = 4, TN = 2;
+    constexpr int A_BYTES = CZ_T * CZ_RB;
+    constexpr int PPW = (2 * CZ_T / 8) / NW;  // 1-KiB LDS-DMA pieces (8 rows) per wave per stage = 8
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int slots = per_x / nqt;
+    if (jx >= slots * nqt) return;
+    const int qtile = jx % nqt;
+    const int64_t u0 = xcd + 8 * (jx / nqt), ustep = 8 * slots;
+    const int my_ntiles = u0 < count ? (int)((count - u0 + ustep - 1) / ustep) : 0;
+    const int KT = K / 64;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+
+    float thr_m[TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) thr_m[m] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + wr * 128 + 32 * m + fr];
+
+    // LDS-DMA: piece p (1 KiB = 8 rows x 128 B) of a stage; pieces 0..31 = query rows, 32..63 = index rows.
+    // The swizzle is applied on the per-lane SOURCE address; the LDS destination is linear.
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* src[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + NW * i;
+        const bool isA = piece < 32;
+        const int trow = (isA ? piece : piece - 32) * 8 + prow;
+        dst[i] = (isA ? 0 : A_BYTES) + (isA ? piece : piece - 32) * 1024;
+        if (isA) src[i] = reinterpret_cast<const char*>(qh + (size_t)(qtile * CZ_T + trow) * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);
+    }
+    auto tile_of = [&](int ti) -> int64_t {
+        const int64_t u = u0 + (int64_t)ti * ustep;
+        return (STAGE0 ? u : u + u / 3 + 1) * stride;
+    };
+    auto set_src = [&](int ti) {
+        const int64_t r0 = tile_of(ti) * CZ_T;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + NW * i;
+            if (piece >= 32) {
+                const int trow = (piece - 32) * 8 + prow;
+                int64_t grow = r0 + trow;
+                grow = grow < ntotal ? grow : ntotal - 1;
+                src[i] = reinterpret_cast<const char*>(xh + (size_t)grow * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);
+            }
+        }
+    };
+#define CZ_ISSUE(KT_, SLOT_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                                \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * CZ_RB), \
+                                         (__attribute__((address_space(3))) void*)(smem + (SLOT_) * CZ_STAGE + dst[i]), 16, 0, 0); \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int it_tile = 0, it_kt = 0, gi = 0;
+    set_src(0);
+    CZ_ISSUE(0, 0)
+    gi = 1;
+    if (++it_kt == KT) {
+        it_kt = 0;
+        if (++it_tile < my_ntiles) set_src(it_tile);
+    }
+    int ct_tile = 0, kt = 0;
+    for (int g = 0; g < total; ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // stage g landed for every wave; the slot of stage g-1 is free
+        if (gi < total) {
+            CZ_ISSUE(it_kt, gi & 1)
+            ++gi;
+            if (++it_kt == KT) {
+                it_kt = 0;
+                if (++it_tile < my_ntiles) set_src(it_tile);
+            }
+        }
+        const char* Ab = smem + (g & 1) * CZ_STAGE;
+        const char* Bb = Ab + A_BYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v4f a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + 32 * m + fr, 2 * c + fh));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + 32 * n + fr, 2 * c + fh));
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    // MFMA rows <- index rows, MFMA columns <- queries: lane (fr, fh) holds query fr and
+                    // index rows (r&3) + 8(r>>2) + 4 fh of the 32-row tile in register r
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, b[n]),
+                                                                        __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
+        }
+        if (++kt == KT) {
+            const int64_t tile = tile_of(ct_tile);
+            const int64_t row0 = tile * CZ_T + wc * 64 + 4 * fh;
+            if constexpr (STAGE0) {
+                const int64_t u = u0 + (int64_t)ct_tile * ustep;  // tile ordinal inside the stage
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + 32 * m + fr) * CZ_CAP + (size_t)u * CZ_T + wc * 64 + 4 * fh;
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = 32 * n + (r & 3) + 8 * (r >> 2);
+                            const bool ok = row0 + ro < ntotal;
+                            cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;
+                            cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;
+                        }
+                }
+            } else {
+                bool any = false;
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) any |= acc[m][n][r] >= thr_m[m];
+                if (__ballot(any) != 0ull) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) {
+                        const int q = qtile * CZ_T + wr * 128 + 32 * m + fr;
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[m][n][r];
+                                if (v >= thr_m[m]) {
+                                    const int64_t row = row0 + 32 * n + (r & 3) + 8 * (r >> 2);
+                                    if (row < ntotal) {
+                                        const int slot = atomicAdd(&cand_n[q], 1);
+                                        if (slot < CZ_CAP) {
+                                            cand_s[(size_t)q * CZ_CAP + slot] = v;
+                                            cand_i[(size_t)q * CZ_CAP + slot] = (uint32_t)row;
+                                        }
+                                    }
+                                }
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            kt = 0;
+            ++ct_tile;
+        }
+    }
+#undef CZ_ISSUE
+}
+
+// Block-wide bitonic sort of P (power of two, <= CZ_CAP) LDS entries, best first: score desc, id asc.
+__device__ __forceinline__ void cz_bitonic(float* s, uint32_t* id, int P, int tid) {
+    for (int size = 2; size <= P; size <<= 1)
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (P >> 1); t += 256) {
+                const int lo = ((t & ~(st - 1)) << 1) | (t & (st - 1));
+                const int hi = lo | st;
+                const bool desc = (lo & size) == 0;
+                const float sl = s[lo], sh = s[hi];
+                const uint32_t il = id[lo], ih = id[hi];
+                const bool hi_better = better<uint32_t>(sh, ih, sl, il);
+                if (hi_better == desc) {
+                    s[lo] = sh; s[hi] = sl;
+                    id[lo] = ih; id[hi] = il;
+                }
+            }
+        }
+    __syncthreads();
+}
+
+// One block per query, between the stages of the cascade (FINAL = false): sort the candidate buffer, take the
+// k-th best coarse score Tc, publish thr = Tc - 2 eps and keep only the entries >= thr.  After the last stage
+// (FINAL = true): rescore the band exactly against the fp32 rows and write the top-k.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
+                                                       int* __restrict__ cand_n, float* __restrict__ thr,
+                                                       int* __restrict__ flags, int* __restrict__ nflag,
+                                                       int* __restrict__ flag_list, const float* __restrict__ qnorm2,
+                                                       const int* __restrict__ maxn2_bits, int k,
+                                                       const float* __restrict__ qpad, const float* __restrict__ xb,
+                                                       int dpad, int64_t id_base, float* __restrict__ D,
+                                                       int64_t* __restrict__ I) {
+    __shared__ float s[CZ_CAP];
+    __shared__ uint32_t id[CZ_CAP];
+    __shared__ int cnt;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_raw = cand_n[q];
+    const bool overflow = n_raw > CZ_CAP;
+    const int n = min(n_raw, CZ_CAP);
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        s[i] = i < n ? cand_s[(size_t)q * CZ_CAP + i] : -INFINITY;
+        id[i] = i < n ? cand_i[(size_t)q * CZ_CAP + i] : kInvalidRow;
+    }
+    if (tid == 0) cnt = 0;
+    cz_bitonic(s, id, P, tid);
+    const float Tc = n >= k ? s[k - 1] : -INFINITY;
+    const float eps = (0.0078125f + 0.00048828125f) * sqrtf(qnorm2[q]) * sqrtf(__int_as_float(*maxn2_bits)) + 1e-30f;
+    const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
+    int c = 0;
+    for (int i = tid; i < n; i += 256) c += (s[i] >= thr_new && id[i] != kInvalidRow) ? 1 : 0;
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    const int m = cnt;  // the band is a prefix of the sorted buffer
+    if constexpr (!FINAL) {
+        for (int i = tid; i < m; i += 256) {
+            cand_s[(size_t)q * CZ_CAP + i] = s[i];
+            cand_i[(size_t)q * CZ_CAP + i] = id[i];
+        }
+        if (tid == 0) {
+            cand_n[q] = m;
+            thr[q] = thr_new;
+            if (overflow) flags[q] = 1;
+        }
+    } else {
+        const bool bad = overflow || flags[q] != 0 || m > CZ_RMAX;
+        if (bad && tid == 0) flag_list[atomicAdd(nflag, 1)] = q;
+        const int R = min(m, CZ_RMAX);
+        __syncthreads();
+        // exact fp32 scores of the band rows: one wave per row, fixed summation order
+        const float4* qv = reinterpret_cast<const float4*>(qpad + (size_t)q * dpad);
+        for (int cidx = wave; cidx < R; cidx += 4) {
+            const float4* xv = reinterpret_cast<const float4*>(xb + (size_t)id[cidx] * dpad);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int j = lane; j < (dpad >> 2); j += 64) {
+                const float4 x = xv[j], y = qv[j];
+                a0 = fmaf(x.x, y.x, a0);
+                a1 = fmaf(x.y, y.y, a1);
+                a2 = fmaf(x.z, y.z, a2);
+                a3 = fmaf(x.w, y.w, a3);
+            }
+            const float e = wave_allsum((a0 + a1) + (a2 + a3));
+            if (lane == 0) s[cidx] = e;
+        }
+        int P2 = 2;
+        while (P2 < R) P2 <<= 1;
+        __syncthreads();
+        for (int i = R + tid; i < P2; i += 256) {
+            s[i] = -INFINITY;
+            id[i] = kInvalidRow;
+        }
+        cz_bitonic(s, id, P2, tid);
+        for (int i = tid; i < k; i += 256) {
+            const bool ok = i < R && id[i] != kInvalidRow;
+            D[(size_t)q * k + i] = ok ? s[i] : -FLT_MAX;
+            I[(size_t)q * k + i] = ok ? id_base + (int64_t)id[i] : (int64_t)-1;
+        }
+    }
+}

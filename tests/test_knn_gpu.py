@@ -225,6 +225,81 @@ def test_mfma_duplicates_ties():
         assert I[r][:2].tolist() == [r, r + 300] and D[r][0] == D[r][1]
 
 
+# ---- coarse bf16 scan + exact rescoring (the default batched path): adversarial inputs ----------
+def _check_against_oracle(x, q, k, normalize, what):
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(x.shape[1])
+    ix.add(x, normalize=normalize)
+    D, I = ix.search(q, k, normalize=normalize)
+    ref = ko.FlatIndexOracle(x.shape[1], 0)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if normalize else (x, q)
+    ref.add(xr)
+    Dr, Ir = ref.search(qr, k)
+    D64 = ref.rescore64(qr, np.where(Ir < 0, 0, Ir))
+    assert_topk_matches(D, I, Dr, Ir, D64, what)
+    ix.close()
+    return D, I
+
+
+def test_coarse_band_overflow_falls_back_to_exact():
+    # 6000 copies of one row: every copy ties for the top -> the candidate band overflows the
+    # rescoring buffer and the flagged queries are re-run on the exact path (lowest ids win the tie)
+    base = synth.rows(3000, 768, 21)
+    x = np.concatenate([base[:1500], np.repeat(base[7:8], 6000, axis=0), base[1500:]], axis=0)
+    q = np.concatenate([base[7:8] + 0.01 * synth.rows(3, 768, 22), synth.rows(37, 768, 23)], axis=0)
+    D, I = _check_against_oracle(x, q, 10, True, "duplicate flood")
+    assert I[0].tolist() == [7] + list(range(1500, 1509))
+
+
+def test_coarse_clustered_rows_dense_bands():
+    # tight clusters (cosine spread ~1e-3 inside a cluster): all 400 members of the query's cluster
+    # fall inside the coarse error band of the k-th best and are rescored exactly
+    cent = synth.rows(20, 768, 31)
+    x = np.repeat(cent, 400, axis=0) + 0.05 * synth.rows(8000, 768, 32)
+    q = cent[:18] + 0.02 * synth.rows(18, 768, 33)
+    q = np.concatenate([q, synth.rows(14, 768, 34)], axis=0)
+    _check_against_oracle(x, q, 10, True, "clustered")
+
+
+def test_coarse_raw_inner_product_wide_norms():
+    # un-normalised rows with norms spread over 3 decades: the error bound scales with max ||row||
+    x = synth.rows(12000, 768, 41) * (10.0 ** (3.0 * np.random.default_rng(1).random((12000, 1)) - 1.5)).astype(np.float32)
+    q = synth.rows(48, 768, 42) * 3.0
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=False)
+    D, I = ix.search(q, 10, normalize=False)
+    ref = ko.FlatIndexOracle(768, 0)
+    ref.add(x)
+    Dr, Ir = ref.search(q, 10)
+    assert (I == Ir).mean() > 0.999 and np.allclose(D, Dr, rtol=1e-5, atol=1e-3)
+    ix.close()
+
+
+@pytest.mark.parametrize("n,nq,k", [(9000, 40, 100), (9000, 33, 128), (700, 4200, 10), (257, 513, 3)])
+def test_coarse_large_k_and_query_chunks(n, nq, k):
+    _run_case(n, 768, nq, k, 0, True, seed=n + k)
+
+
+def test_coarse_and_split_paths_agree(monkeypatch):
+    # same batch through the single-query sweeps (exact fp32 VALU path): identical ids, scores to 1e-5
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    x = synth.rows(30000, 768, 51)
+    q = synth.rows(64, 768, 52)
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=True)
+    D, I = ix.search(q, 10, normalize=True)
+    for r in range(0, 64, 9):
+        d1, i1 = ix.search(q[r:r + 1], 10, normalize=True)
+        assert i1[0].tolist() == I[r].tolist() and np.allclose(d1[0], D[r], atol=1e-5)
+    ix.close()
+
+
 def test_invalid_arguments_raise():
     from claude_semantic_search_amd.flat_index import IndexFlatIP
 

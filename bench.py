@@ -338,36 +338,59 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
     kernels = {}
-    for name in ("knn_scan_mfma", "knn_scan_small", "knn_merge", "knn_merge_parts"):
+    for name in ("knn_scan_coarse_main", "knn_coarse_cascade", "knn_scan_mfma", "knn_scan_small", "knn_merge",
+                 "knn_merge_parts"):
         ms, n = nat.prof_read(name)
         if n:
             kernels[name] = (ms, n)
-    dom = max(kernels, key=lambda k_: kernels[k_][0]) if kernels else None
+    cand = {k_: v for k_, v in kernels.items() if k_ != "knn_coarse_cascade"}
+    dom = max(cand, key=lambda k_: cand[k_][0]) if cand else None
     roofline = None
     if dom:
         ms, n = kernels[dom]
         avg_s = ms / n / 1e3
-        sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one sweep of this rank's shard
-        if dom == "knn_scan_mfma":
+        sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one fp32 sweep of this rank's shard
+        if dom == "knn_scan_coarse_main":
+            # last stage of the cascade (k_scan_coarse<false,true>): the row tiles t with t % 4 != 0, i.e.
+            # 3/4 of the shard, one bf16 MFMA product per (row, query, 16 k); see css_knn_coarse.h
+            ntiles = -(-shard // 256)
+            main_tiles = (ntiles - 1) - (ntiles - 1) // 4
+            main_rows = min(main_tiles * 256, shard)
+            flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
+            sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
+            roofline = {"bound": "mfma", "kernel": "k_scan_coarse<false,true> (main stage of the cascade)",
+                        "achieved": flops / avg_s / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None,
+                        "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows,
+                        "hbm_GBps": sweep_bytes / avg_s / 1e9,
+                        "arithmetic": "bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_32x32x16_bf16; "
+                                      "candidates rescored in fp32",
+                        "executed_mfma_TFLOPs": flops * (-(-args.nq // 256) * 256 / args.nq) / avg_s / 1e12}
+            if "knn_coarse_cascade" in kernels:
+                cms, cn = kernels["knn_coarse_cascade"]
+                roofline["cascade_ms"] = cms / cn           # all stages + selects + rescoring of one search
+                roofline["cascade_algorithmic_TFLOPs"] = 2.0 * shard * args.dim * args.nq / (cms / cn / 1e3) / 1e12
+        elif dom == "knn_scan_mfma":
             nq_launch = args.nq * args.steps / n     # queries served per launch
             flops = 2.0 * shard * args.dim * nq_launch   # ALGORITHMIC (fp32 dot-product) flops
             split = os.environ.get("CSS_KNN_BATCH", "split") != "fp32"
-            # split mode: every fp32-grade product costs 4 bf16 MFMA products, so the roof of
-            # the emulation is the dense bf16 peak / 4; fp32 mode: the fp32-input MFMA peak.
-            peak = BF16_MFMA_PEAK_TF / 4.0 if split else FP32_MFMA_PEAK_TF
+            # split mode: every fp32-grade product costs 3 bf16 MFMA products (h.h + h.l + l.h), so the
+            # roof of the emulation is the dense bf16 peak / 3; fp32 mode: the fp32-input MFMA peak.
+            peak = BF16_MFMA_PEAK_TF / 3.0 if split else FP32_MFMA_PEAK_TF
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flops / avg_s / 1e12, "peak": peak,
                         "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": None,
                         "launches": n, "avg_ms": ms / n, "hbm_GBps": sweep_bytes / avg_s / 1e9,
-                        "arithmetic": ("bf16x4 split-operand MFMA, fp32 accumulate (peak = 2500/4)" if split
+                        "arithmetic": ("bf16x3 split-operand MFMA, fp32 accumulate (peak = 2500/3)" if split
                                        else "fp32-input MFMA (exact fp32)"),
-                        "executed_mfma_TFLOPs": (4.0 if split else 1.0) * flops * (-(-args.nq // 128) * 128 / args.nq) / avg_s / 1e12}
+                        "executed_mfma_TFLOPs": (3.0 if split else 1.0) * flops * (-(-args.nq // 128) * 128 / args.nq) / avg_s / 1e12}
         else:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": sweep_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": sweep_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "launches": n, "avg_ms": ms / n}
     if roofline:
+        roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
         wl = {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k}
-        tr = pmc_traffic("k_scan_mfma" if dom == "knn_scan_mfma" else "k_scan_small", wl)
+        tr = pmc_traffic({"knn_scan_mfma": "k_scan_mfma", "knn_scan_coarse_main": "k_scan_coarse<false, true>"}.get(dom, "k_scan_small"), wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
@@ -436,7 +459,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 (index and scores fp32; batched scan multiplies bf16-split operands, fp32 accumulate)",
+            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by a bf16 MFMA scan with a "
+                     "rigorous error band, candidates rescored in fp32)",
             "data": "synthetic",
             "config": {"workload": f"{args.rows}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
                                    f"top-{args.k}, index row-partitioned over {world} GPU(s)",

@@ -1154,6 +1154,7 @@ int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb
 // split-bf16 MFMA (CSS_KNN_BATCH=split, and the fallback) or exact fp32 MFMA (CSS_KNN_BATCH=fp32, verification).
 int g_knn_batch_split = -1;
 int g_knn_batch_coarse = -1;
+int g_knn_dbg = -1;  // CSS_KNN_DBG: timing experiments on k_scan_coarse (results are wrong when set)
 
 template <int METRIC>
 int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
@@ -1257,31 +1258,30 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         CSS_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
+    typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
+                            int, int64_t, int64_t, int);
+    const scan_fn f_stage0 = k_scan_coarse<true, false>, f_mid = k_scan_coarse<false, false>, f_main = k_scan_coarse<false, true>;
     static bool attr_set = false;
     if (!attr_set) {
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_coarse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (scan_fn f : {f_stage0, f_mid, f_main})
+            CSS_HIP_TRY(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int grid = std::max(8, ix->num_cus / 8 * 8);
+    if (g_knn_dbg < 0) {
+        const char* m = getenv("CSS_KNN_DBG");
+        g_knn_dbg = m ? atoi(m) : 0;
+    }
     ProfScope all("knn_coarse_cascade", st);
     for (int64_t s = s0;; s /= 4) {
         const bool stage0 = s == s0;
         const int64_t W = (ntiles + s - 1) / s;
         const int64_t count = stage0 ? W : (W - 1) - (W - 1) / 4;
         if (count > 0) {
-            if (stage0) {
-                hipLaunchKernelGGL((k_scan_coarse<true, false>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
-                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
-            } else if (s == 1) {
-                ProfScope ps("knn_scan_coarse_main", st);
-                hipLaunchKernelGGL((k_scan_coarse<false, true>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
-                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
-            } else {
-                hipLaunchKernelGGL((k_scan_coarse<false, false>), dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr,
-                                   ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s);
-            }
+            const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
+            ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
+            hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g_knn_dbg);
             CSS_LAUNCH_CHECK();
         }
         if (s == 1) {

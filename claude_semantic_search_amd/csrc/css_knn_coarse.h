@@ -23,6 +23,11 @@
 // to a per-query candidate buffer (lane-local atomicAdd + two stores; ~3k + band rows per stage).  The hot
 // kernel is then a plain persistent bf16 GEMM (the encoder's LDS-DMA ring) whose epilogue is 128 compares.
 // A query whose buffer or band overflows is flagged and re-run on the exact path by the host.
+//
+// Measured on MI355X (10M x 768, 1000 queries): main stage 11.6 ms; LDS-DMA only 7.4 ms (~49 GB/s per CU into
+// LDS, the same with one or two stages in flight: a bandwidth, not a latency limit), MFMA + LDS reads only
+// 7.4 ms, epilogue ~0.8 ms.  A variant with separate 3-slot query / 2-slot row rings (DMA issue spread between
+// the MFMAs and staggered between the two waves of a SIMD) was 5 % slower and is not kept.
 #pragma once
 
 constexpr int CZ_T = 256;            // rows per tile and queries per tile
@@ -53,6 +58,65 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
     flags[i] = 0;
 }
 
+// Epilogue of one 256x256 tile of k_scan_coarse (uses the kernel's locals).
+#define CZ_EPILOGUE()                                                                                        \
+            const int64_t tile = tile_of(ct_tile);                                                                     \
+            const int64_t row0 = tile * CZ_T + wc * 64 + 4 * fh;                                                       \
+            if (dbg & 1) {                                                                                             \
+            } else if constexpr (STAGE0) {                                                                             \
+                const int64_t u = u0 + (int64_t)ct_tile * ustep;                                                       \
+_Pragma("unroll")                                                                                                      \
+                for (int m = 0; m < TM; ++m) {                                                                         \
+                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + 32 * m + fr) * CZ_CAP + (size_t)u * CZ_T + wc * 64 + 4 * fh; \
+_Pragma("unroll")                                                                                                      \
+                    for (int n = 0; n < TN; ++n)                                                                       \
+_Pragma("unroll")                                                                                                      \
+                        for (int r = 0; r < 16; ++r) {                                                                 \
+                            const int ro = 32 * n + (r & 3) + 8 * (r >> 2);                                            \
+                            const bool ok = row0 + ro < ntotal;                                                        \
+                            cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;                                           \
+                            cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;                                \
+                        }                                                                                              \
+                }                                                                                                      \
+            } else {                                                                                                   \
+                bool any = false;                                                                                      \
+_Pragma("unroll")                                                                                                      \
+                for (int m = 0; m < TM; ++m)                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int n = 0; n < TN; ++n)                                                                       \
+_Pragma("unroll")                                                                                                      \
+                        for (int r = 0; r < 16; ++r) any |= acc[m][n][r] >= thr_m[m];                                  \
+                if (__ballot(any) != 0ull) {                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int m = 0; m < TM; ++m) {                                                                     \
+                        const int q = qtile * CZ_T + wr * 128 + 32 * m + fr;                                           \
+_Pragma("unroll")                                                                                                      \
+                        for (int n = 0; n < TN; ++n)                                                                   \
+_Pragma("unroll")                                                                                                      \
+                            for (int r = 0; r < 16; ++r) {                                                             \
+                                const float v = acc[m][n][r];                                                          \
+                                if (v >= thr_m[m]) {                                                                   \
+                                    const int64_t row = row0 + 32 * n + (r & 3) + 8 * (r >> 2);                        \
+                                    if (row < ntotal) {                                                                \
+                                        const int slot = atomicAdd(&cand_n[q], 1);                                     \
+                                        if (slot < CZ_CAP) {                                                           \
+                                            cand_s[(size_t)q * CZ_CAP + slot] = v;                                     \
+                                            cand_i[(size_t)q * CZ_CAP + slot] = (uint32_t)row;                         \
+                                        }                                                                              \
+                                    }                                                                                  \
+                                }                                                                                      \
+                            }                                                                                          \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+_Pragma("unroll")                                                                                                      \
+            for (int m = 0; m < TM; ++m)                                                                               \
+_Pragma("unroll")                                                                                                      \
+                for (int n = 0; n < TN; ++n)                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;                                                   \
+    do {} while (0)
+
 // One stage of the cascade.  Grid = one block of 8 waves per CU (persistent).  Block -> (query tile, stream of
 // row tiles): the nqt blocks that share a row tile sit on one XCD (blockIdx % 8) and walk side by side, so the
 // tile's rows are fetched from HBM once per XCD L2.
@@ -65,7 +129,10 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      const unsigned short* __restrict__ qh,
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
-                                                     int64_t ntotal, int K, int nqt, int64_t count, int64_t stride) {
+                                                     int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
+                                                     int dbg) {
+    // dbg (CSS_KNN_DBG, timing experiments only): bit0 skip the epilogue, bit1 skip MFMA + LDS reads,
+    // bit2 skip the LDS-DMA loads
     constexpr int NW = 8, WN = 4, TM = 4, TN = 2;
     constexpr int A_BYTES = CZ_T * CZ_RB;
     constexpr int PPW = (2 * CZ_T / 8) / NW;  // 1-KiB LDS-DMA pieces (8 rows) per wave per stage = 8
@@ -135,7 +202,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 
     int it_tile = 0, it_kt = 0, gi = 0;
     set_src(0);
-    CZ_ISSUE(0, 0)
+    if (!(dbg & 4)) {
+        CZ_ISSUE(0, 0)
+    }
     gi = 1;
     if (++it_kt == KT) {
         it_kt = 0;
@@ -146,7 +215,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage g landed for every wave; the slot of stage g-1 is free
         if (gi < total) {
-            CZ_ISSUE(it_kt, gi & 1)
+            if (!(dbg & 4)) {
+                CZ_ISSUE(it_kt, gi & 1)
+            }
             ++gi;
             if (++it_kt == KT) {
                 it_kt = 0;
@@ -155,6 +226,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         }
         const char* Ab = smem + (g & 1) * CZ_STAGE;
         const char* Bb = Ab + A_BYTES;
+        if (!(dbg & 2))
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             v4f a[TM], b[TN];
@@ -172,60 +244,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                                         __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
         }
         if (++kt == KT) {
-            const int64_t tile = tile_of(ct_tile);
-            const int64_t row0 = tile * CZ_T + wc * 64 + 4 * fh;
-            if constexpr (STAGE0) {
-                const int64_t u = u0 + (int64_t)ct_tile * ustep;  // tile ordinal inside the stage
-#pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + 32 * m + fr) * CZ_CAP + (size_t)u * CZ_T + wc * 64 + 4 * fh;
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ro = 32 * n + (r & 3) + 8 * (r >> 2);
-                            const bool ok = row0 + ro < ntotal;
-                            cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;
-                            cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;
-                        }
-                }
-            } else {
-                bool any = false;
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) any |= acc[m][n][r] >= thr_m[m];
-                if (__ballot(any) != 0ull) {
-#pragma unroll
-                    for (int m = 0; m < TM; ++m) {
-                        const int q = qtile * CZ_T + wr * 128 + 32 * m + fr;
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float v = acc[m][n][r];
-                                if (v >= thr_m[m]) {
-                                    const int64_t row = row0 + 32 * n + (r & 3) + 8 * (r >> 2);
-                                    if (row < ntotal) {
-                                        const int slot = atomicAdd(&cand_n[q], 1);
-                                        if (slot < CZ_CAP) {
-                                            cand_s[(size_t)q * CZ_CAP + slot] = v;
-                                            cand_i[(size_t)q * CZ_CAP + slot] = (uint32_t)row;
-                                        }
-                                    }
-                                }
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            CZ_EPILOGUE();
             kt = 0;
             ++ct_tile;
         }

@@ -1223,16 +1223,39 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
 
 // Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [0, nq) of ix->qpad; nq <= 4096.
 // Returns the number of flagged queries (their ids in `flagged`) whose result must be recomputed on the exact path.
+template <int NQ>
+int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, bool stage0,
+                           hipStream_t st) {
+    const size_t lds = (size_t)NQ * ix->dpad * sizeof(float);
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
+    if (ix->dpad == 768) {
+        auto kern = k_sweep_coarse<NQ, 6>;
+        if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
+                           ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
+    } else {
+        auto kern = k_sweep_coarse<NQ, 0>;
+        if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
+                           ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
+    }
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+// sweep = true: 1..4 queries through the HBM-bound bf16 sweep (k_sweep_coarse) instead of the MFMA scan.
 int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st,
-                       std::vector<int>* flagged) {
+                       std::vector<int>* flagged, bool sweep) {
     const float* qpad = ix->qpad + (size_t)q0 * ix->dpad;
     const float* qnorm2 = ix->qnorm2 + q0;
     D_dev += (size_t)q0 * k;
     I_dev += (size_t)q0 * k;
-    const int nq_pad = (nq + CZ_T - 1) / CZ_T * CZ_T;
-    const int nqt = nq_pad / CZ_T;
+    const int nq_pad = sweep ? nq : (nq + CZ_T - 1) / CZ_T * CZ_T;
+    const int nqt = sweep ? 1 : nq_pad / CZ_T;
+    // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
+    const float eps_rel = sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f;
     int rc;
-    if ((rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
+    if (!sweep && (rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cthr, &ix->cthr_cap, (size_t)nq_pad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, (size_t)nq_pad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cflags, &ix->cflags_cap, (size_t)2 * nq_pad + 1)) != CSS_OK) return rc;
@@ -1249,10 +1272,12 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int64_t n0 = (ntiles + s0 - 1) / s0;
 
     {
-        const int64_t ne = (int64_t)nq_pad * ix->dpad;
-        hipLaunchKernelGGL(k_rows_to_bf16, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qh,
-                           (int64_t)nq, (int64_t)nq_pad, ix->dpad);
-        CSS_LAUNCH_CHECK();
+        if (!sweep) {
+            const int64_t ne = (int64_t)nq_pad * ix->dpad;
+            hipLaunchKernelGGL(k_rows_to_bf16, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qh,
+                               (int64_t)nq, (int64_t)nq_pad, ix->dpad);
+            CSS_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T));
         CSS_LAUNCH_CHECK();
@@ -1272,12 +1297,18 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         const char* m = getenv("CSS_KNN_DBG");
         g_knn_dbg = m ? atoi(m) : 0;
     }
-    ProfScope all("knn_coarse_cascade", st);
+    ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
     for (int64_t s = s0;; s /= 4) {
         const bool stage0 = s == s0;
         const int64_t W = (ntiles + s - 1) / s;
         const int64_t count = stage0 ? W : (W - 1) - (W - 1) / 4;
-        if (count > 0) {
+        if (count > 0 && sweep) {
+            ProfScope ps(s == 1 && !stage0 ? "knn_sweep_coarse_main" : "knn_sweep_coarse_stage", st);
+            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, stage0, st);
+            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, stage0, st);
+            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, stage0, st);
+            if (rc != CSS_OK) return rc;
+        } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
@@ -1286,13 +1317,13 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
         if (s == 1) {
             hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, k, qpad, ix->xb, ix->dpad,
+                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, k, qpad, ix->xb, ix->dpad,
                                ix->id_base, D_dev, I_dev);
             CSS_LAUNCH_CHECK();
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, k, qpad, ix->xb, ix->dpad,
+                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, k, qpad, ix->xb, ix->dpad,
                            ix->id_base, D_dev, I_dev);
         CSS_LAUNCH_CHECK();
     }
@@ -1351,15 +1382,20 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         const char* m = getenv("CSS_KNN_BATCH");
         g_knn_batch_coarse = (m && (std::string(m) == "fp32" || std::string(m) == "split")) ? 0 : 1;
     }
-    if (g_knn_batch_coarse && nq > 16 && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
+    // coarse paths need room for k rows in stage 0 (always true) and the bf16 shadow rows
+    if (g_knn_batch_coarse && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
         std::vector<int> flagged;
-        for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
-            const int nqc = (int)std::min<int64_t>(4096, nq - q0);
-            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, &flagged)) != CSS_OK) return rc;
+        if (nq <= 4) {  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
+            if ((rc = launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, &flagged, true)) != CSS_OK) return rc;
+        } else {
+            for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
+                const int nqc = (int)std::min<int64_t>(4096, nq - q0);
+                if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, &flagged, false)) != CSS_OK) return rc;
+            }
         }
         if (flagged.empty()) return CSS_OK;
         // candidate buffer / band overflow (e.g. thousands of duplicate rows): exact path for those queries
-        if (flagged.size() > 32 && k <= kMfmaMaxK) return launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st);
+        if (flagged.size() > 32 && nq > 16 && k <= kMfmaMaxK) return launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st);
         if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
         for (int q : flagged)
             if ((rc = search_chunk_small(ix, q, 1, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;

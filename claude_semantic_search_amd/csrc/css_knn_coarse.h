@@ -252,6 +252,119 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 #undef CZ_ISSUE
 }
 
+// The same cascade stage for 1..4 queries: an HBM-bound sweep over the bf16 shadow rows (half the bytes of the
+// fp32 sweep of k_scan_small).  16 lanes per row read 16 B each (8 bf16 = 256 B contiguous per row and column
+// step), the bf16 are widened to fp32 by a shift, multiplied with the fp32 query from LDS and reduced over the
+// 16 lanes with 4 DPP adds; lane j of the row group then tests query j's score against its threshold.
+// Two groups of 4 rows per iteration keep 2*TT 16-B loads in flight per lane.  TT = dpad/128 (0: run-time).
+template <int NQ, int TT>
+__global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __restrict__ xh,
+                                                      const float* __restrict__ qpad, const float* __restrict__ thr,
+                                                      float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
+                                                      int* __restrict__ cand_n, int64_t ntotal, int dpad, int nq,
+                                                      int64_t count, int64_t stride, int stage0) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][dpad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
+    for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq ? qpad[i] : 0.f;
+    float my_thr = INFINITY;  // lane `sub` looks after query `sub`
+    if (sub < nq && !stage0) my_thr = thr[sub];
+    __syncthreads();
+    const int steps = TT > 0 ? TT : (dpad + 127) / 128;
+    for (int64_t u = blockIdx.x; u < count; u += gridDim.x) {
+        const int64_t tile = (stage0 ? u : u + u / 3 + 1) * stride;
+        const int64_t row_base = tile * CZ_T + wave * 64;
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
+            // NQ > 1: keep the query reads inside the loop (hoisted, they take 48 NQ registers and the
+            // occupancy with them); one query stays in registers
+            if constexpr (NQ > 1) asm volatile("" ::: "memory");
+            const int64_t rowA = row_base + it * 4 + rg, rowB = rowA + 4;
+            const uint4* pa = reinterpret_cast<const uint4*>(xh + (size_t)(rowA < ntotal ? rowA : ntotal - 1) * dpad) + sub;
+            const uint4* pb = reinterpret_cast<const uint4*>(xh + (size_t)(rowB < ntotal ? rowB : ntotal - 1) * dpad) + sub;
+            float sa[NQ], sb[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
+            if constexpr (TT > 0) {
+                uint4 va[TT], vb[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    va[t] = pa[16 * t];
+                    vb[t] = pb[16 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const unsigned wa[4] = {va[t].x, va[t].y, va[t].z, va[t].w};
+                    const unsigned wb[4] = {vb[t].x, vb[t].y, vb[t].z, vb[t].w};
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const float4 q0 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub);
+                        const float4 q1 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub + 4);
+                        const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
+                            sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
+                            sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
+                            sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
+                        }
+                    }
+                }
+            } else {
+                for (int t = 0; t < steps; ++t) {
+                    if (128 * t + 8 * sub >= dpad) break;  // dpad is a multiple of 64: whole 16-B chunks
+                    const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
+                    const unsigned wa[4] = {xa.x, xa.y, xa.z, xa.w};
+                    const unsigned wb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const float* qv = qs + j * dpad + 128 * t + 8 * sub;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
+                            sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
+                            sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
+                            sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
+                        }
+                    }
+                }
+            }
+            float ma = 0.f, mb = 0.f;  // score of query `sub` for this lane's row
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
+                if (sub == j) {
+                    ma = ra;
+                    mb = rb;
+                }
+            }
+            if (sub < nq) {
+                if (stage0) {
+                    const size_t o = (size_t)sub * CZ_CAP + (size_t)u * CZ_T + wave * 64 + it * 4 + rg;
+                    cand_s[o] = rowA < ntotal ? ma : -INFINITY;
+                    cand_i[o] = rowA < ntotal ? (uint32_t)rowA : kInvalidRow;
+                    cand_s[o + 4] = rowB < ntotal ? mb : -INFINITY;
+                    cand_i[o + 4] = rowB < ntotal ? (uint32_t)rowB : kInvalidRow;
+                } else {
+                    if (ma >= my_thr && rowA < ntotal) {
+                        const int slot = atomicAdd(&cand_n[sub], 1);
+                        if (slot < CZ_CAP) {
+                            cand_s[(size_t)sub * CZ_CAP + slot] = ma;
+                            cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowA;
+                        }
+                    }
+                    if (mb >= my_thr && rowB < ntotal) {
+                        const int slot = atomicAdd(&cand_n[sub], 1);
+                        if (slot < CZ_CAP) {
+                            cand_s[(size_t)sub * CZ_CAP + slot] = mb;
+                            cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowB;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Block-wide bitonic sort of P (power of two, <= CZ_CAP) LDS entries, best first: score desc, id asc.
 __device__ __forceinline__ void cz_bitonic(float* s, uint32_t* id, int P, int tid) {
     for (int size = 2; size <= P; size <<= 1)
@@ -281,7 +394,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                                                        int* __restrict__ cand_n, float* __restrict__ thr,
                                                        int* __restrict__ flags, int* __restrict__ nflag,
                                                        int* __restrict__ flag_list, const float* __restrict__ qnorm2,
-                                                       const int* __restrict__ maxn2_bits, int k,
+                                                       const int* __restrict__ maxn2_bits, float eps_rel, int k,
                                                        const float* __restrict__ qpad, const float* __restrict__ xb,
                                                        int dpad, int64_t id_base, float* __restrict__ D,
                                                        int64_t* __restrict__ I) {
@@ -301,7 +414,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     if (tid == 0) cnt = 0;
     cz_bitonic(s, id, P, tid);
     const float Tc = n >= k ? s[k - 1] : -INFINITY;
-    const float eps = (0.0078125f + 0.00048828125f) * sqrtf(qnorm2[q]) * sqrtf(__int_as_float(*maxn2_bits)) + 1e-30f;
+    const float eps = eps_rel * sqrtf(qnorm2[q]) * sqrtf(__int_as_float(*maxn2_bits)) + 1e-30f;
     const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
     int c = 0;
     for (int i = tid; i < n; i += 256) c += (s[i] >= thr_new && id[i] != kInvalidRow) ? 1 : 0;

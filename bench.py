@@ -415,14 +415,26 @@ def main():
             fence()
             dt = (time.perf_counter() - t0) / reps
             nat.prof_enable(False)
-            ms, n = nat.prof_read("knn_scan_small")
-            gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
-            tr = pmc_traffic("k_scan_small<1,", {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
-            extra[f"nq1_k{kq}"] = {"latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
-                                   "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": gbs / HBM_PEAK_GBS if gbs else None,
+            ms, n = nat.prof_read("knn_sweep_coarse_main")
+            if n:   # coarse sweep over the bf16 shadow rows: main stage = the row tiles t with t % 4 != 0
+                ntiles = -(-shard // 256)
+                main_rows = min(((ntiles - 1) - (ntiles - 1) // 4) * 256, shard)
+                kbytes = main_rows * args.dim * 2
+                kname = "k_sweep_coarse<1, 6, true>"
+            else:   # fp32 sweep (no shadow rows)
+                ms, n = nat.prof_read("knn_scan_small")
+                kbytes = shard * args.dim * 4
+                kname = "k_scan_small<1,"
+            gbs = kbytes / (ms / n / 1e3) / 1e9 if n else None
+            cms, cn = nat.prof_read("knn_sweep_cascade")
+            tr = pmc_traffic(kname, {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
+            extra[f"nq1_k{kq}"] = {"latency_ms": dt * 1e3, "cascade_ms": cms / cn if cn else None,
+                                   "scan_kernel_ms": ms / n if n else None,
+                                   "roofline": {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                                                 "traffic": tr["bytes_per_launch"] if tr else None,
-                                                "algorithmic_bytes_per_launch": shard * args.dim * 4}}
+                                                "algorithmic_bytes_per_launch": kbytes},
+                                   "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
             nat.prof_reset()
 
     cpu = None

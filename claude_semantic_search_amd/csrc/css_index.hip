@@ -62,6 +62,7 @@ struct css_index {
     int* cflags = nullptr;    size_t cflags_cap = 0;    // [nq_pad] flags | [nq_pad] flagged list | [1] count
     float* cand_s = nullptr;  size_t cand_s_cap = 0;
     uint32_t* cand_i = nullptr; size_t cand_i_cap = 0;
+    int* cpace = nullptr;     size_t cpace_cap = 0;     // sibling pacing counters [stage][group]
     std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
     std::mutex ws_mu;      // workspaces + own stream are single-user
 };
@@ -1223,24 +1224,27 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
 
 // Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [0, nq) of ix->qpad; nq <= 4096.
 // Returns the number of flagged queries (their ids in `flagged`) whose result must be recomputed on the exact path.
+template <int NQ, int TT, bool MAIN>
+int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, bool stage0,
+                          hipStream_t st) {
+    const size_t lds = (size_t)NQ * ix->dpad * sizeof(float);
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
+    auto kern = k_sweep_coarse<NQ, TT, MAIN>;
+    if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
+                       ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
 template <int NQ>
 int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, bool stage0,
                            hipStream_t st) {
-    const size_t lds = (size_t)NQ * ix->dpad * sizeof(float);
-    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
-    if (ix->dpad == 768) {
-        auto kern = k_sweep_coarse<NQ, 6>;
-        if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
-    } else {
-        auto kern = k_sweep_coarse<NQ, 0>;
-        if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
-    }
-    CSS_LAUNCH_CHECK();
-    return CSS_OK;
+    const bool main_stage = stride == 1 && !stage0;
+    if (ix->dpad == 768)
+        return main_stage ? launch_sweep_coarse_t<NQ, 6, true>(ix, qpad, nq, count, stride, stage0, st)
+                          : launch_sweep_coarse_t<NQ, 6, false>(ix, qpad, nq, count, stride, stage0, st);
+    return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, stage0, st);
 }
 
 // sweep = true: 1..4 queries through the HBM-bound bf16 sweep (k_sweep_coarse) instead of the MFMA scan.
@@ -1284,7 +1288,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int);
+                            int, int64_t, int64_t, int*, int);
     const scan_fn f_stage0 = k_scan_coarse<true, false>, f_mid = k_scan_coarse<false, false>, f_main = k_scan_coarse<false, true>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1297,6 +1301,17 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         const char* m = getenv("CSS_KNN_DBG");
         g_knn_dbg = m ? atoi(m) : 0;
     }
+    static int pacing = -1;  // CSS_KNN_PACE=0 disables the sibling pacing of k_scan_coarse (A/B experiments)
+    if (pacing < 0) {
+        const char* m = getenv("CSS_KNN_PACE");
+        pacing = (m && m[0] == '0') ? 0 : 1;
+    }
+    constexpr int kPaceGroups = 512, kPaceStages = 20;
+    if (!sweep && pacing) {
+        if ((rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
+        CSS_HIP_TRY(hipMemsetAsync(ix->cpace, 0, sizeof(int) * kPaceGroups * kPaceStages, st));
+    }
+    int stage_idx = 0;
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
     for (int64_t s = s0;; s /= 4) {
         const bool stage0 = s == s0;
@@ -1311,10 +1326,12 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
+            int* pace = (pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g_knn_dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, pace, g_knn_dbg);
             CSS_LAUNCH_CHECK();
         }
+        ++stage_idx;
         if (s == 1) {
             hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
                                ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, k, qpad, ix->xb, ix->dpad,
@@ -1453,7 +1470,7 @@ int css_index_free(css_index* ix) {
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i};
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     (void)hipStreamDestroy(ix->stream);

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
-                                                     int dbg) {
+                                                     int* __restrict__ pace_cnt, int dbg) {
     // dbg (CSS_KNN_DBG, timing experiments only): bit0 skip the epilogue, bit1 skip MFMA + LDS reads,
     // bit2 skip the LDS-DMA loads
     constexpr int NW = 8, WN = 4, TM = 4, TN = 2;
@@ -155,6 +155,16 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     float thr_m[TM];
 #pragma unroll
     for (int m = 0; m < TM; ++m) thr_m[m] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + wr * 128 + 32 * m + fr];
+
+    // Sibling pacing (speed only, never needed for correctness): the nqt blocks that walk the same row tiles
+    // drift apart (appends, DMA jitter); once they are more than ~2 K-steps apart the tile's rows have left
+    // the XCD's 4 MiB L2 (2 MiB stream through it per step) and every sibling fetches them again (measured
+    // 2.6x the row bytes from HBM/MALL).  Each block announces "3 steps from the end of tile i" on a
+    // per-group counter, reads it one step later (asynchronously) and, before issuing the first stage of tile
+    // i+1, waits for its siblings -- a bounded spin, after which the block stops pacing for good.
+    int* my_cnt = pace_cnt ? pace_cnt + xcd * slots + jx / nqt : nullptr;
+    bool pace = my_cnt != nullptr && nqt > 1 && KT >= 4 && wave == 0;
+    int seen = 0;
 
     // LDS-DMA: piece p (1 KiB = 8 rows x 128 B) of a stage; pieces 0..31 = query rows, 32..63 = index rows.
     // The swizzle is applied on the per-lane SOURCE address; the LDS destination is linear.
@@ -213,6 +223,23 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     int ct_tile = 0, kt = 0;
     for (int g = 0; g < total; ++g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pace && ct_tile + 1 < my_ntiles) {
+            if (kt == KT - 3) {
+                if (lane == 0) __hip_atomic_fetch_add(my_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (kt == KT - 2) {
+                if (lane == 0) seen = __hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (kt == KT - 1) {
+                const int target = nqt * (ct_tile + 1);
+                int spins = 0;
+                int v = __builtin_amdgcn_readfirstlane(seen);
+                while (v < target && spins < 64) {
+                    __builtin_amdgcn_s_sleep(8);
+                    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    ++spins;
+                }
+                if (v < target) pace = false;  // siblings not co-resident (or far behind): stop waiting for them
+            }
+        }
         __builtin_amdgcn_s_barrier();  // stage g landed for every wave; the slot of stage g-1 is free
         if (gi < total) {
             if (!(dbg & 4)) {
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 // step), the bf16 are widened to fp32 by a shift, multiplied with the fp32 query from LDS and reduced over the
 // 16 lanes with 4 DPP adds; lane j of the row group then tests query j's score against its threshold.
 // Two groups of 4 rows per iteration keep 2*TT 16-B loads in flight per lane.  TT = dpad/128 (0: run-time).
-template <int NQ, int TT>
+template <int NQ, int TT, bool MAIN>  // MAIN: the last (stride 1) stage gets its own name in profiles
 __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __restrict__ xh,
                                                       const float* __restrict__ qpad, const float* __restrict__ thr,
                                                       float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,

@@ -6,21 +6,24 @@
 // (src/storage.py:424-436).
 //
 // HBM layout: xb[cap][dpad] fp32 row-major, dpad = dim rounded up to 64 floats
-// (768 -> 768, i.e. 3072 B rows = 3 x 1 KiB wave loads), zero padded, plus
-// xnorm2[cap] (squared norms, used by the L2 MFMA path).  Capacity grows
+// (768 -> 768, i.e. 3072 B rows), zero padded, xnorm2[cap] (squared norms) and,
+// for inner-product indexes while it fits, a bf16 shadow copy xh[cap][dpad] of
+// the rows (coarse scans read it; see css_knn_coarse.h).  Capacity grows
 // geometrically or is reserved up front (css_index_reserve) so a 10M..80M row
 // shard is allocated once.
 //
 // Kernels (DESIGN.md has the rooflines):
-//   k_ingest_rows   one wave per row: optional synthetic generation, fused
-//                   x/(||x||+1e-8), zero pad, squared norm.           HBM bound
-//   k_scan_small    1..16 queries: 16 lanes per row (4 rows per wave
-//                   instruction, 256 B contiguous per row segment), VALU FMAs,
-//                   DPP row reduction, block-shared sorted top-k lists in LDS
-//                   with a grid-wide monotone threshold for pruning.  HBM bound
-//   k_scan_mfma     >16 queries: 128x128x32 tiles on v_mfma_f32_32x32x2_f32 (exact
-//                   fp32), LDS-staged and swizzled, fused top-k epilogue.    MFMA bound
-//   k_merge_final   per query: merge the per-block lists into the final top-k.
+//   k_ingest_rows      one wave per row: optional synthetic generation, fused
+//                      x/(||x||+1e-8), zero pad, squared norm, bf16 shadow.  HBM bound
+//   k_scan_coarse,     default search path: coarse bf16 scores (MFMA scan for
+//   k_sweep_coarse,    batches, HBM-bound sweep for 1..4 queries) inside a rigorous
+//   k_coarse_select    error band, then exact fp32 rescoring of the band (css_knn_coarse.h)
+//   k_scan_small       exact fp32 sweep for 1..16 queries (L2 metric, no shadow rows,
+//                      flagged queries): 16 lanes per row, VALU FMAs, DPP row reduction,
+//                      block-shared sorted top-k lists in LDS, grid-wide threshold.   HBM bound
+//   k_scan_mfma_split  exact batched scan on split bf16 operands (3 MFMAs per product);
+//   k_scan_mfma        the same on fp32-input MFMA (CSS_KNN_BATCH=fp32, verification)
+//   k_merge_final      per query: merge the per-block lists into the final top-k.
 #include "css_common.h"
 #include "css_knn_kernels.h"
 #include "../../include/css_synth.h"

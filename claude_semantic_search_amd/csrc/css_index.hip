@@ -1292,7 +1292,14 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
                             int, int64_t, int64_t, int*, int);
-    const scan_fn f_stage0 = k_scan_coarse<true, false>, f_mid = k_scan_coarse<false, false>, f_main = k_scan_coarse<false, true>;
+    if (g_knn_dbg < 0) {
+        const char* m = getenv("CSS_KNN_DBG");
+        g_knn_dbg = m ? atoi(m) : 0;
+    }
+    // (the DBG instantiations honour CSS_KNN_DBG; the product kernels carry no timing switches)
+    const scan_fn f_stage0 = k_scan_coarse<true, false>;
+    const scan_fn f_mid = g_knn_dbg ? k_scan_coarse<false, false, true> : k_scan_coarse<false, false>;
+    const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true> : k_scan_coarse<false, true>;
     static bool attr_set = false;
     if (!attr_set) {
         for (scan_fn f : {f_stage0, f_mid, f_main})
@@ -1300,10 +1307,6 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         attr_set = true;
     }
     const int grid = std::max(8, ix->num_cus / 8 * 8);
-    if (g_knn_dbg < 0) {
-        const char* m = getenv("CSS_KNN_DBG");
-        g_knn_dbg = m ? atoi(m) : 0;
-    }
     static int pacing = -1;  // CSS_KNN_PACE=0 disables the sibling pacing of k_scan_coarse (A/B experiments)
     if (pacing < 0) {
         const char* m = getenv("CSS_KNN_PACE");

@@ -124,15 +124,17 @@ _Pragma("unroll")                                                               
 // query column per 32-query tile (4 queries per lane), 32 registers of 64 index rows each.
 // STAGE0: every score is written to slot (tile ordinal * 256 + row in tile); otherwise scores >= thr are
 // appended.  MAIN only gives the last (stride 1, 3/4 of the rows) stage its own name in profiles.
-template <bool STAGE0, bool MAIN>
+template <bool STAGE0, bool MAIN, bool DBG = false>
 __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __restrict__ xh,
                                                      const unsigned short* __restrict__ qh,
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
-                                                     int* __restrict__ pace_cnt, int dbg) {
-    // dbg (CSS_KNN_DBG, timing experiments only): bit0 skip the epilogue, bit1 skip MFMA + LDS reads,
-    // bit2 skip the LDS-DMA loads
+                                                     int* __restrict__ pace_cnt, int dbg_arg) {
+    // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
+    // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
+    // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads
+    const int dbg = DBG ? dbg_arg : 0;
     constexpr int NW = 8, WN = 4, TM = 4, TN = 2;
     constexpr int A_BYTES = CZ_T * CZ_RB;
     constexpr int PPW = (2 * CZ_T / 8) / NW;  // 1-KiB LDS-DMA pieces (8 rows) per wave per stage = 8
@@ -253,23 +255,51 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         }
         const char* Ab = smem + (g & 1) * CZ_STAGE;
         const char* Bb = Ab + A_BYTES;
-        if (!(dbg & 2))
+#define CZ_READ(A_, B_, C_)                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                                    \
+        A_[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + 32 * m + fr, 2 * (C_) + fh));                    \
+    _Pragma("unroll") for (int n = 0; n < TN; ++n)                                                                    \
+        B_[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + 32 * n + fr, 2 * (C_) + fh));
+#define CZ_MFMA(A_, B_)                                                                                                \
+    _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                                    \
+        _Pragma("unroll") for (int n = 0; n < TN; ++n)                                                                \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, B_[n]),                      \
+                                                                __builtin_bit_cast(v8bf, A_[m]), acc[m][n], 0, 0, 0);
+        // MFMA rows <- index rows, MFMA columns <- queries: lane (fr, fh) holds query fr and index rows
+        // (r&3) + 8(r>>2) + 4 fh of the 32-row tile in register r
+        if constexpr (!DBG) {
+            // (explicitly double-buffered fragment reads pinned with sched_barrier measured 2 % slower than
+            // hipcc's own read / wait / 4-MFMA groups: LDS latency is not what bounds this loop)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            v4f a[TM], b[TN];
+            for (int c = 0; c < 4; ++c) {
+                v4f a[TM], b[TN];
+                CZ_READ(a, b, c)
+                CZ_MFMA(a, b)
+            }
+        } else if (!(dbg & 2)) {
 #pragma unroll
-            for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + 32 * m + fr, 2 * c + fh));
+            for (int c = 0; c < 4; ++c) {
+                v4f a[TM], b[TN];
+                if (!(dbg & 16)) {
+                    CZ_READ(a, b, c)
+                } else {
 #pragma unroll
-            for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + 32 * n + fr, 2 * c + fh));
+                    for (int m = 0; m < TM; ++m) a[m] = v4f{1.f, 2.f, 3.f, 4.f};
 #pragma unroll
-            for (int m = 0; m < TM; ++m)
+                    for (int n = 0; n < TN; ++n) b[n] = v4f{1.f, 2.f, 3.f, 4.f};
+                }
+                if (dbg & 8) {
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    // MFMA rows <- index rows, MFMA columns <- queries: lane (fr, fh) holds query fr and
-                    // index rows (r&3) + 8(r>>2) + 4 fh of the 32-row tile in register r
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, b[n]),
-                                                                        __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < TM; ++m) asm volatile("" ::"v"(a[m]));
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) asm volatile("" ::"v"(b[n]));
+                } else {
+                    CZ_MFMA(a, b)
+                }
+            }
         }
+#undef CZ_READ
+#undef CZ_MFMA
         if (++kt == KT) {
             CZ_EPILOGUE();
             kt = 0;

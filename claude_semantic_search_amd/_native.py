@@ -12,7 +12,9 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libcss_hip.so"
+# CSS_HIP_LIB: development aid -- another build of the same library (A/B timing of two source states in one
+# GPU session, tools/build_variant.sh); the product always loads the in-tree file.
+LIB_PATH = Path(os.environ["CSS_HIP_LIB"]) if os.environ.get("CSS_HIP_LIB") else _PKG / "libcss_hip.so"
 
 CSS_OK = 0
 CSS_ERR_INVALID = -1

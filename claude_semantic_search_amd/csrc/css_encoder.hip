@@ -267,6 +267,7 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
     return CSS_OK;
 }
 
+int g_enc_resid = 2;       // CSS_ENC_RESID: residual stream storage in bf16 mode (see forward_typed)
 int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
 int g_gemm_big_tiles = 1;
 int g_gemm_ring = 2;       // CSS_GEMM_RING: 2 = 2 stages x 128 B rows (default: fewest barriers, measured fastest), 3 = 3 x 64 B, 4 = 4 x 64 B  // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
@@ -309,6 +310,31 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         CSS_LAUNCH_CHECK();
     }
     const int maxL = c.max_seq_len;
+    // Residual stream storage (bf16 mode): g_enc_resid 0 = fp32 rows (x32) + fp32 branch outputs,
+    // 1 = bf16 residual (the row the next GEMM reads anyway) + fp32 branch outputs, 2 = both bf16.
+    const int rmode = BF ? g_enc_resid : 0;
+    // attention-output / FFN2 projection into `pre32` (fp32, or bf16 rows when rmode == 2)
+    auto launch_branch_out = [&](const void* a, const void* w, const float* bias, int K, const char* prof) -> int {
+        if (rmode == 2) return launch_gemm<TIn, EPI_QKV>(a, w, bias, e->pre32, T, H, K, 0, 1.0f, e->num_cus, st, prof);
+        return launch_gemm<TIn, EPI_RESID>(a, w, bias, e->pre32, T, H, K, 0, 1.0f, e->num_cus, st, prof);
+    };
+    // x = LN(pre + x); `last`: the fp32 row is needed by the pooling
+    auto launch_ln = [&](const float* g, const float* b, bool last) -> int {
+        ProfScope ps("enc_layernorm", st);
+        const dim3 grid((T + 3) / 4), blk(256);
+        bf16_t* o16 = BF ? (bf16_t*)e->x16 : nullptr;
+        if (rmode == 0)
+            hipLaunchKernelGGL((k_layernorm<768, float, float>), grid, blk, 0, st, (const float*)e->pre32, (const float*)e->x32, g, b,
+                               c.ln_eps, e->x32, o16, T);
+        else if (rmode == 1)
+            hipLaunchKernelGGL((k_layernorm<768, float, bf16_t>), grid, blk, 0, st, (const float*)e->pre32, (const bf16_t*)e->x16, g, b,
+                               c.ln_eps, last ? e->x32 : (float*)nullptr, o16, T);
+        else
+            hipLaunchKernelGGL((k_layernorm<768, bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)e->pre32, (const bf16_t*)e->x16, g, b,
+                               c.ln_eps, last ? e->x32 : (float*)nullptr, o16, T);
+        CSS_LAUNCH_CHECK();
+        return CSS_OK;
+    };
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& L = e->layers[li];
         const void* xin = BF ? e->x16 : (const void*)e->x32;
@@ -328,27 +354,15 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
             CSS_LAUNCH_CHECK();
         }
         const void* wo = BF ? (const void*)L.wo_h : (const void*)L.wo;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ctx, wo, L.bo, e->pre32, T, H, H, 0, 1.0f, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
-            return rc;
-        {
-            ProfScope ps("enc_layernorm", st);
-            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, e->x32, L.ln1g, L.ln1b,
-                               c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
-            CSS_LAUNCH_CHECK();
-        }
+        if ((rc = launch_branch_out(e->ctx, wo, L.bo, H, "enc_gemm_o")) != CSS_OK) return rc;
+        if ((rc = launch_ln(L.ln1g, L.ln1b, false)) != CSS_OK) return rc;
         xin = BF ? e->x16 : (const void*)e->x32;
         const void* w1 = BF ? (const void*)L.w1_h : (const void*)L.w1;
         if ((rc = launch_gemm<TIn, EPI_GELU>(xin, w1, L.b1, e->ffn, T, F, H, 0, 1.0f, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         const void* w2 = BF ? (const void*)L.w2_h : (const void*)L.w2;
-        if ((rc = launch_gemm<TIn, EPI_RESID>(e->ffn, w2, L.b2, e->pre32, T, H, F, 0, 1.0f, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
-            return rc;
-        {
-            ProfScope ps("enc_layernorm", st);
-            hipLaunchKernelGGL(k_layernorm<768>, dim3((T + 3) / 4), dim3(256), 0, st, e->pre32, e->x32, L.ln2g, L.ln2b,
-                               c.ln_eps, e->x32, BF ? (bf16_t*)e->x16 : nullptr, T);
-            CSS_LAUNCH_CHECK();
-        }
+        if ((rc = launch_branch_out(e->ffn, w2, L.b2, F, "enc_gemm_ffn2")) != CSS_OK) return rc;
+        if ((rc = launch_ln(L.ln2g, L.ln2b, li == c.num_layers - 1)) != CSS_OK) return rc;
     }
     {
         ProfScope ps("enc_pool", st);
@@ -395,6 +409,7 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     if (const char* t = getenv("CSS_GEMM_TILE")) g_gemm_big_tiles = atoi(t) != 128;
     if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
     if (const char* t = getenv("CSS_GEMM_RING")) g_gemm_ring = atoi(t);
+    if (const char* t = getenv("CSS_ENC_RESID")) g_enc_resid = atoi(t);
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;

@@ -98,10 +98,27 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
     }
 }
 
-// LayerNorm of fp32 rows: LN(in + resid) (the GEMM epilogue added the bias; the residual
-// add lives here, where the access is perfectly coalesced, so the GEMM epilogue is store-only).
-template <int H>
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ resid,
+// LayerNorm of token rows: LN(in + resid) (the GEMM epilogue added the bias; the residual add lives
+// here, where the access is perfectly coalesced, so the GEMM epilogue is store-only).  The arithmetic
+// is fp32; TPre / TRes are the storage types of the GEMM output and of the residual stream (float, or
+// bf16 in the product mode: the residual then is the same bf16 row the next GEMM reads, and the kernel
+// moves 6 B per element instead of 14).  out32 may be null (only the last LN of the stack feeds the
+// fp32 pooling).
+template <typename T>
+__device__ __forceinline__ float4 ln_load4(const T* row, int idx);
+template <>
+__device__ __forceinline__ float4 ln_load4<float>(const float* row, int idx) {
+    return reinterpret_cast<const float4*>(row)[idx];
+}
+template <>
+__device__ __forceinline__ float4 ln_load4<bf16_t>(const bf16_t* row, int idx) {
+    const ushort4 h = reinterpret_cast<const ushort4*>(row)[idx];
+    return make_float4(__uint_as_float((unsigned)h.x << 16), __uint_as_float((unsigned)h.y << 16),
+                       __uint_as_float((unsigned)h.z << 16), __uint_as_float((unsigned)h.w << 16));
+}
+
+template <int H, typename TPre, typename TRes>
+__global__ __launch_bounds__(256) void k_layernorm(const TPre* __restrict__ in, const TRes* __restrict__ resid,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps,
                                                    float* __restrict__ out32, bf16_t* __restrict__ out16, int T) {
@@ -109,13 +126,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const float4* x4 = reinterpret_cast<const float4*>(in + (size_t)t * H);
-    const float4* r4 = reinterpret_cast<const float4*>(resid + (size_t)t * H);
+    const TPre* xrow = in + (size_t)t * H;
+    const TRes* rrow = resid + (size_t)t * H;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float4 a = x4[lane + 64 * i], b = r4[lane + 64 * i];
+        const float4 a = ln_load4<TPre>(xrow, lane + 64 * i), b = ln_load4<TRes>(rrow, lane + 64 * i);
         v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
         o.y = (v[i].y - mean) * rstd * g.y + b.y;
         o.z = (v[i].z - mean) * rstd * g.z + b.z;
         o.w = (v[i].w - mean) * rstd * g.w + b.w;
-        reinterpret_cast<float4*>(out32 + (size_t)t * H)[lane + 64 * i] = o;
+        if (out32) reinterpret_cast<float4*>(out32 + (size_t)t * H)[lane + 64 * i] = o;
         if (out16) {
             ushort4 h;
             h.x = f2bf(o.x); h.y = f2bf(o.y); h.z = f2bf(o.z); h.w = f2bf(o.w);

@@ -437,6 +437,52 @@ def main():
                                    "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
             nat.prof_reset()
 
+        # ---- extra: the parity mode (every score formed in fp32 by the scan kernels) on the same index ----
+        index.set_search_mode("exact_fp32")
+        try:
+            ex = {}
+            for _ in range(2):
+                index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            fence()
+            nat.prof_reset()
+            nat.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            fence()
+            dt = (time.perf_counter() - t0) / 10
+            nat.prof_enable(False)
+            ms, n = nat.prof_read("knn_scan_small")
+            gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
+            tr = pmc_traffic("k_scan_small<1,", {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
+            ex["nq1_k10"] = {"latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
+                             "roofline": {"bound": "hbm", "kernel": "k_scan_small<1,12,IP>", "achieved": gbs,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                                          "traffic": tr["bytes_per_launch"] if tr else None,
+                                          "algorithmic_bytes_per_launch": shard * args.dim * 4}}
+            nat.prof_reset()
+            index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            fence()
+            nat.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            fence()
+            dt = (time.perf_counter() - t0) / 2
+            nat.prof_enable(False)
+            ms, n = nat.prof_read("knn_scan_mfma")
+            fl = 2.0 * shard * args.dim * args.nq
+            ex[f"nq{args.nq}_k{args.k}"] = {
+                "queries_per_s": args.nq / dt, "ms_per_batch": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
+                "roofline": {"bound": "mfma", "kernel": "k_scan_mfma_split<IP,8,8>",
+                             "achieved": fl / (ms / n / 1e3) / 1e12 if n else None, "peak": BF16_MFMA_PEAK_TF / 3.0,
+                             "unit": "TFLOP/s", "frac": fl / (ms / n / 1e3) / 1e12 / (BF16_MFMA_PEAK_TF / 3.0) if n else None,
+                             "arithmetic": "fp32 operands split into bf16 pairs, 3 MFMA products per fp32-grade product"}}
+            nat.prof_reset()
+            extra["exact_fp32_mode"] = ex
+        finally:
+            index.set_search_mode("auto")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_knn(args, log)

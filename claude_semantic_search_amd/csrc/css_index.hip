@@ -46,6 +46,7 @@ struct css_index {
     float* xnorm2 = nullptr;
     unsigned short* xh = nullptr;  // bf16 shadow rows [cap][dpad] for the coarse scan (nullptr: not kept)
     int shadow = -1;               // -1 undecided, 0 off, 1 on (CSS_KNN_SHADOW, HBM headroom)
+    int search_mode = CSS_SEARCH_AUTO;
     int* maxn2 = nullptr;          // device scalar: bits of max ||row||^2 (coarse error bound)
     hipStream_t stream = nullptr;
     int num_cus = 256;
@@ -1406,7 +1407,7 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         g_knn_batch_coarse = (m && (std::string(m) == "fp32" || std::string(m) == "split")) ? 0 : 1;
     }
     // coarse paths need room for k rows in stage 0 (always true) and the bf16 shadow rows
-    if (g_knn_batch_coarse && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
+    if (g_knn_batch_coarse && ix->search_mode == CSS_SEARCH_AUTO && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
         std::vector<int> flagged;
         if (nq <= 4) {  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
             if ((rc = launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, &flagged, true)) != CSS_OK) return rc;
@@ -1525,6 +1526,14 @@ int css_index_metric(const css_index* ix, int* metric) {
 int css_index_device(const css_index* ix, int* device) {
     CSS_REQUIRE(ix && device, "css_index_device: NULL argument");
     *device = ix->device;
+    return CSS_OK;
+}
+
+int css_index_set_search_mode(css_index* ix, int mode) {
+    CSS_REQUIRE(ix, "css_index_set_search_mode: NULL index");
+    CSS_REQUIRE(mode == CSS_SEARCH_AUTO || mode == CSS_SEARCH_EXACT_FP32, "css_index_set_search_mode: unknown mode %d", mode);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    ix->search_mode = mode;
     return CSS_OK;
 }
 

@@ -110,6 +110,14 @@ class IndexFlat:
                                                  1 if normalize else 0, ctypes.c_void_p(D_ptr),
                                                  ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
 
+    def set_search_mode(self, mode: str) -> None:
+        """``"auto"`` (default: bf16 candidate scan + exact fp32 rescoring when the index keeps
+        shadow rows) or ``"exact_fp32"`` (every score formed in fp32 by the scan kernels)."""
+        modes = {"auto": 0, "exact_fp32": 1}
+        if mode not in modes:
+            raise ValueError(f"unknown search mode {mode!r}")
+        nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))
+
     def set_id_base(self, base: int) -> None:
         nat.check(nat.lib().css_index_set_id_base(self._handle(), int(base)))
 

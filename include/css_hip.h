@@ -104,6 +104,13 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * error band and return exact fp32 scores of the rescored candidates (same
  * results as the fp32 kernels).  The _dev form enqueues on `stream`; on that
  * candidate path it also waits for the stream once per call (overflow check). */
+/* Search path: CSS_SEARCH_AUTO (default) selects candidates with the bf16 scan and
+ * rescores them in fp32 whenever the index keeps shadow rows; CSS_SEARCH_EXACT_FP32
+ * forms every score in fp32 inside the scan kernels (the parity mode of the tests;
+ * also what L2 indexes and indexes without shadow rows always use). */
+#define CSS_SEARCH_AUTO 0
+#define CSS_SEARCH_EXACT_FP32 1
+int css_index_set_search_mode(css_index* ix, int mode);
 int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
                      float* D_host, int64_t* I_host);
 int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,

@@ -65,3 +65,12 @@ def test_10m_query_batch_mfma_path_and_agreement(big_index):
     assert np.abs(Ds - Db[:4]).max() < 1e-5
     same = Is == Ib[:4]
     assert same.mean() > 0.97                    # near-ties may swap between the two arithmetic orders
+    # the parity mode (every score formed in fp32 by the scan kernels) returns the same answer at full size
+    big_index.set_search_mode("exact_fp32")
+    try:
+        De, Ie = big_index.search(q[:40], K)     # split-operand MFMA scan
+        D1, I1 = big_index.search(q[:2], K)      # fp32 sweep
+    finally:
+        big_index.set_search_mode("auto")
+    assert np.abs(De - Db[:40]).max() < 1e-5 and (Ie == Ib[:40]).mean() > 0.97
+    assert np.abs(D1 - Db[:2]).max() < 1e-5 and (I1 == Ib[:2]).mean() > 0.9

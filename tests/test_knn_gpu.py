@@ -22,13 +22,17 @@ def _run_case(n, d, nq, k, metric, normalize, seed=1):
     hip = IndexFlat(d, metric)
     hip.add(x, normalize=normalize)
     assert hip.ntotal == n
-    D, I = hip.search(q, k, normalize=normalize)
     ref = ko.FlatIndexOracle(d, metric)
     xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if normalize else (x, q)
     ref.add(xr)
     Dr, Ir = ref.search(qr, k)
     D64 = ref.rescore64(qr, np.where(Ir < 0, 0, Ir))
-    assert_topk_matches(D, I, Dr, Ir, D64, f"n={n} d={d} nq={nq} k={k} metric={metric}")
+    # both search paths against the oracle: "exact_fp32" (every score formed in fp32 by the scan kernels: the
+    # parity mode) and "auto" (the product default: bf16 candidate scan + exact fp32 rescoring where available)
+    for mode in ("exact_fp32", "auto"):
+        hip.set_search_mode(mode)
+        D, I = hip.search(q, k, normalize=normalize)
+        assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}")
     hip.close()
 
 
@@ -121,8 +125,12 @@ def test_committed_goldens_on_hip():
         ix = IndexFlat(int(g["d"]), metric)
         ix.add_synthetic(int(g["n"]), int(g["seed_x"]), 0, normalize=norm)
         q = synth.rows(int(g["nq"]), int(g["d"]), int(g["seed_q"]))
-        D, I = ix.search(q, int(g["k"]), normalize=norm)
-        assert_topk_matches(D, I, g["D"], g["I"].astype(np.int64), g["D64"], name)
+        for mode in ("exact_fp32", "auto"):
+            ix.set_search_mode(mode)
+            D, I = ix.search(q, int(g["k"]), normalize=norm)
+            assert_topk_matches(D, I, g["D"], g["I"].astype(np.int64), g["D64"], f"{name} [{mode}]")
+            D1, I1 = ix.search(q[:3], int(g["k"]), normalize=norm)   # the few-query path of the same mode
+            assert_topk_matches(D1, I1, g["D"][:3], g["I"][:3].astype(np.int64), g["D64"][:3], f"{name} [{mode}, 3 queries]")
 
 
 def test_device_synthetic_rows_equal_host_generator():

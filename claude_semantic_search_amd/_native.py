@@ -89,6 +89,9 @@ PROTOTYPES = {
     "css_index_export": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "css_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "css_index_search_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "css_index_search_masked": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "css_index_search_masked_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
     "css_merge_topk_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "css_encoder_create": (c_int, [POINTER(EncoderCfg), c_int, POINTER(c_void_p)]),
     "css_encoder_free": (c_int, [c_void_p]),

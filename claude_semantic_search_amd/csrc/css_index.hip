@@ -47,6 +47,8 @@ struct css_index {
     unsigned short* xh = nullptr;  // bf16 shadow rows [cap][dpad] for the coarse scan (nullptr: not kept)
     int shadow = -1;               // -1 undecided, 0 off, 1 on (CSS_KNN_SHADOW, HBM headroom)
     int search_mode = CSS_SEARCH_AUTO;
+    const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
+    uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
     int* maxn2 = nullptr;          // device scalar: bits of max ||row||^2 (coarse error bound)
     hipStream_t stream = nullptr;
     int num_cus = 256;
@@ -137,7 +139,8 @@ template <int NQ, int TT, int METRIC>
 __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict__ xb, const float* __restrict__ qpad,
                                                     int64_t ntotal, int T_rt, int k, int64_t groups_per_block,
                                                     int* __restrict__ gthr, float* __restrict__ part_s,
-                                                    uint32_t* __restrict__ part_i, int nq_real) {
+                                                    uint32_t* __restrict__ part_i, int nq_real,
+                                                    const uint32_t* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = TT > 0 ? TT : T_rt;  // float4 steps of 16 lanes: dpad = 64*T
     const int dpad = T * 64;
@@ -177,8 +180,10 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
         }
 
         const int64_t row = g * 4 + rsub;
-        const bool valid = row < ntotal;
-        const int64_t rowc = valid ? row : ntotal - 1;
+        const bool in_range = row < ntotal;
+        const int64_t rowc = in_range ? row : ntotal - 1;
+        // masked search: rows whose bit is clear can never be candidates (filter / tombstone push-down)
+        const bool valid = in_range && (mask == nullptr || ((mask[rowc >> 5] >> (rowc & 31)) & 1u));
         const float4* xr = xb + rowc * (int64_t)(T * 16) + sub;
 
         float acc[NQ];
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
                                                       const float* __restrict__ qpad, int nq_real, int64_t ntotal,
                                                       int dpad, int k, int nstrips, int nqtiles,
                                                       int64_t tiles_per_strip, int* __restrict__ gthr,
-                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i) {
+                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i,
+                                                      const uint32_t* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                 // [2][128][32]
     float* Bs = As + 2 * MF_BM * MF_BK;                         // [2][128][32]
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
                         const int64_t row = row0 + 32 * m + rr;
                         const float sv = S[rr * 33 + fr];
                         const bool pass = fh == 0 && (full_tile || row < ntotal) && q_base + jq < nq_real &&
+                                          (mask == nullptr || ((mask[row >> 5] >> (row & 31)) & 1u)) &&
                                           sv >= thr_l && sv >= thr_g;
                         unsigned long long mk = __ballot(pass);
                         if (mk == 0ull) continue;
@@ -509,7 +516,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
                                                       const unsigned short* __restrict__ qsplit, int nq_real, int64_t ntotal,
                                                       int dpad, int k, int nstrips, int nqtiles,
                                                       int64_t tiles_per_strip, int* __restrict__ gthr,
-                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i) {
+                                                      float* __restrict__ part_s, uint32_t* __restrict__ part_i,
+                                                      const uint32_t* __restrict__ mask) {
     constexpr int NT = 64 * NW, BM = 32 * MT, BN = 32 * NW;
     constexpr int APASS = BM * 4 / NT;   // A staging passes (rows per pass = NT/4)
     static_assert(NW <= MT && APASS >= 1, "tile shape");
@@ -739,6 +747,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_mfma_split(const float* __rest
                         const int64_t row = row0 + 32 * m + rr;
                         const float sv = S[rr * 32 + fr];
                         const bool pass = fh == 0 && (full_tile || row < ntotal) && q_base + jq < nq_real &&
+                                          (mask == nullptr || ((mask[row >> 5] >> (row & 31)) & 1u)) &&
                                           sv >= thr_l && sv >= thr_g;
                         unsigned long long mk = __ballot(pass);
                         if (mk == 0ull) continue;
@@ -1086,7 +1095,7 @@ int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, in
         CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps("knn_scan_small", st);
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, (const float4*)ix->xb, qpad, ix->ntotal, T, k,
-                       groups_per_block, gthr, ix->part_s, ix->part_i, nq_real);
+                       groups_per_block, gthr, ix->part_s, ix->part_i, nq_real, ix->cur_mask);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1201,12 +1210,12 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
             auto kern = k_scan_mfma_split<METRIC, 8, 8>;
             CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(512), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
         } else {
             auto kern = k_scan_mfma_split<METRIC, 4, 4>;
             CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
         }
         CSS_LAUNCH_CHECK();
     } else {
@@ -1214,7 +1223,7 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
         CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps("knn_scan_mfma", st);
         hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qpad, nq,
-                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i);
+                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
         CSS_LAUNCH_CHECK();
     }
     {
@@ -1236,7 +1245,7 @@ int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t coun
     auto kern = k_sweep_coarse<NQ, TT, MAIN>;
     if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
-                       ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0);
+                       ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0, ix->cur_mask);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1292,7 +1301,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int*, int);
+                            int, int64_t, int64_t, int*, const uint32_t*, int);
     if (g_knn_dbg < 0) {
         const char* m = getenv("CSS_KNN_DBG");
         g_knn_dbg = m ? atoi(m) : 0;
@@ -1335,7 +1344,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, pace, g_knn_dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, pace, ix->cur_mask, g_knn_dbg);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;
@@ -1477,7 +1486,7 @@ int css_index_free(css_index* ix) {
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace};
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     (void)hipStreamDestroy(ix->stream);
@@ -1617,18 +1626,33 @@ int css_index_export(const css_index* cix, int64_t row0, int64_t n, float* x_out
     return CSS_OK;
 }
 
-int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
-                         int64_t* I_dev, void* stream) {
+// RAII: the allow-bitmap of the search in progress (read by the kernel launchers); caller holds ws_mu
+namespace {
+struct MaskScope {
+    css_index* ix;
+    MaskScope(css_index* i, const uint32_t* m) : ix(i) { ix->cur_mask = m; }
+    ~MaskScope() { ix->cur_mask = nullptr; }
+};
+}  // namespace
+
+int css_index_search_masked_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,
+                                const uint32_t* allow_bits_dev, float* D_dev, int64_t* I_dev, void* stream) {
     CSS_REQUIRE(ix, "css_index_search_dev: NULL index");
     CSS_REQUIRE(nq == 0 || (q_dev && D_dev && I_dev), "css_index_search_dev: NULL buffer");
     std::shared_lock<std::shared_mutex> lk(ix->mu);
     std::lock_guard<std::mutex> wl(ix->ws_mu);
     DeviceGuard g(ix->device);
+    MaskScope ms(ix, allow_bits_dev);
     return search_dev_locked(ix, q_dev, nq, k, normalize_q, D_dev, I_dev, (hipStream_t)stream);
 }
 
-int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q, float* D_host,
-                     int64_t* I_host) {
+int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
+                         int64_t* I_dev, void* stream) {
+    return css_index_search_masked_dev(ix, q_dev, nq, k, normalize_q, nullptr, D_dev, I_dev, stream);
+}
+
+int css_index_search_masked(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
+                            const uint32_t* allow_bits_host, float* D_host, int64_t* I_host) {
     CSS_REQUIRE(ix, "css_index_search: NULL index");
     CSS_REQUIRE(nq >= 0, "css_index_search: nq < 0");
     if (nq == 0) return CSS_OK;
@@ -1652,6 +1676,14 @@ int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int 
             ix->out_cap = need;
         }
     }
+    const uint32_t* mask_dev = nullptr;
+    if (allow_bits_host && ix->ntotal > 0) {
+        const size_t words = (size_t)((ix->ntotal + 31) / 32);
+        if ((rc = grow(&ix->mask_ws, &ix->mask_ws_cap, words)) != CSS_OK) return rc;
+        CSS_HIP_TRY(hipMemcpyAsync(ix->mask_ws, allow_bits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+        mask_dev = ix->mask_ws;
+    }
+    MaskScope ms(ix, mask_dev);
     CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, q_host, (size_t)nq * ix->dim * 4, hipMemcpyHostToDevice, ix->stream));
     if ((rc = search_dev_locked(ix, ix->q_raw, nq, k, normalize_q, ix->out_d, ix->out_i, ix->stream)) != CSS_OK)
         return rc;
@@ -1659,6 +1691,11 @@ int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int 
     CSS_HIP_TRY(hipMemcpyAsync(I_host, ix->out_i, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
+}
+
+int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q, float* D_host,
+                     int64_t* I_host) {
+    return css_index_search_masked(ix, q_host, nq, k, normalize_q, nullptr, D_host, I_host);
 }
 
 int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t nq, int k, int metric, float* D,

@@ -58,6 +58,9 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
     flags[i] = 0;
 }
 
+// allow-bitmap test of a masked search (filter / tombstone push-down): bit r&31 of word r>>5
+#define CZ_ALLOWED(MASK_, ROW_) ((MASK_) == nullptr || (((MASK_)[(ROW_) >> 5] >> ((ROW_) & 31)) & 1u))
+
 // Epilogue of one 256x256 tile of k_scan_coarse (uses the kernel's locals).
 #define CZ_EPILOGUE()                                                                                        \
             const int64_t tile = tile_of(ct_tile);                                                                     \
@@ -73,7 +76,7 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                         for (int r = 0; r < 16; ++r) {                                                                 \
                             const int ro = 32 * n + (r & 3) + 8 * (r >> 2);                                            \
-                            const bool ok = row0 + ro < ntotal;                                                        \
+                            const bool ok = row0 + ro < ntotal && CZ_ALLOWED(mask, row0 + ro);                         \
                             cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;                                           \
                             cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;                                \
                         }                                                                                              \
@@ -97,7 +100,7 @@ _Pragma("unroll")                                                               
                                 const float v = acc[m][n][r];                                                          \
                                 if (v >= thr_m[m]) {                                                                   \
                                     const int64_t row = row0 + 32 * n + (r & 3) + 8 * (r >> 2);                        \
-                                    if (row < ntotal) {                                                                \
+                                    if (row < ntotal && CZ_ALLOWED(mask, row)) {                                       \
                                         const int slot = atomicAdd(&cand_n[q], 1);                                     \
                                         if (slot < CZ_CAP) {                                                           \
                                             cand_s[(size_t)q * CZ_CAP + slot] = v;                                     \
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
-                                                     int* __restrict__ pace_cnt, int dbg_arg) {
+                                                     int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
+                                                     int dbg_arg) {
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
     // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads
@@ -319,7 +323,8 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                                                       const float* __restrict__ qpad, const float* __restrict__ thr,
                                                       float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                       int* __restrict__ cand_n, int64_t ntotal, int dpad, int nq,
-                                                      int64_t count, int64_t stride, int stage0) {
+                                                      int64_t count, int64_t stride, int stage0,
+                                                      const uint32_t* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][dpad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
     for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq ? qpad[i] : 0.f;
@@ -395,21 +400,22 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                 }
             }
             if (sub < nq) {
+                const bool okA = rowA < ntotal && CZ_ALLOWED(mask, rowA), okB = rowB < ntotal && CZ_ALLOWED(mask, rowB);
                 if (stage0) {
                     const size_t o = (size_t)sub * CZ_CAP + (size_t)u * CZ_T + wave * 64 + it * 4 + rg;
-                    cand_s[o] = rowA < ntotal ? ma : -INFINITY;
-                    cand_i[o] = rowA < ntotal ? (uint32_t)rowA : kInvalidRow;
-                    cand_s[o + 4] = rowB < ntotal ? mb : -INFINITY;
-                    cand_i[o + 4] = rowB < ntotal ? (uint32_t)rowB : kInvalidRow;
+                    cand_s[o] = okA ? ma : -INFINITY;
+                    cand_i[o] = okA ? (uint32_t)rowA : kInvalidRow;
+                    cand_s[o + 4] = okB ? mb : -INFINITY;
+                    cand_i[o + 4] = okB ? (uint32_t)rowB : kInvalidRow;
                 } else {
-                    if (ma >= my_thr && rowA < ntotal) {
+                    if (ma >= my_thr && okA) {
                         const int slot = atomicAdd(&cand_n[sub], 1);
                         if (slot < CZ_CAP) {
                             cand_s[(size_t)sub * CZ_CAP + slot] = ma;
                             cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowA;
                         }
                     }
-                    if (mb >= my_thr && rowB < ntotal) {
+                    if (mb >= my_thr && okB) {
                         const int slot = atomicAdd(&cand_n[sub], 1);
                         if (slot < CZ_CAP) {
                             cand_s[(size_t)sub * CZ_CAP + slot] = mb;

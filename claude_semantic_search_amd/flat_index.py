@@ -32,6 +32,18 @@ def _as_f32_2d(x, d: int, what: str) -> np.ndarray:
     return a
 
 
+def pack_allow_bits(allow, ntotal: int) -> np.ndarray:
+    """Boolean row mask -> the uint32 bitmap of ``css_index_search_masked`` (bit r & 31 of word r >> 5)."""
+    m = np.asarray(allow)
+    if m.dtype != np.bool_ or m.ndim != 1 or m.shape[0] != ntotal:
+        raise ValueError(f"allow must be a boolean array of ntotal={ntotal} entries")
+    by = np.packbits(m, bitorder="little")
+    words = (ntotal + 31) // 32
+    out = np.zeros(words * 4, dtype=np.uint8)
+    out[: by.shape[0]] = by
+    return out.view("<u4")
+
+
 class IndexFlat:
     """Exact brute-force index in HBM (``faiss.IndexFlat`` semantics)."""
 
@@ -87,9 +99,11 @@ class IndexFlat:
         nat.check(nat.lib().css_index_add_synthetic(self._handle(), int(n), ctypes.c_uint64(seed), int(first_row),
                                                     1 if normalize else 0, ctypes.c_void_p(stream)))
 
-    def search(self, q, k: int, normalize: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, q, k: int, normalize: bool = False, allow=None) -> Tuple[np.ndarray, np.ndarray]:
         """``(D[nq,k] float32, I[nq,k] int64)``; IP descending, L2 ascending squared
-        distances, ``-1`` padded (``src/storage.py:436``)."""
+        distances, ``-1`` padded (``src/storage.py:436``).  ``allow`` (optional boolean array of
+        ``ntotal`` entries) restricts the answer to the rows marked True -- the filter / tombstone
+        push-down the reference approximates by over-fetching (``src/storage.py:438-492``)."""
         a = _as_f32_2d(q, self.d, "search")
         k = int(k)
         if k < 1 or k > nat.MAX_K:
@@ -97,9 +111,13 @@ class IndexFlat:
         nq = a.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
+        bits = None
+        if allow is not None:
+            bits = pack_allow_bits(allow, self.ntotal)
         if nq:
-            nat.check(nat.lib().css_index_search(self._handle(), a.ctypes.data, nq, k, 1 if normalize else 0,
-                                                 D.ctypes.data, I.ctypes.data))
+            nat.check(nat.lib().css_index_search_masked(self._handle(), a.ctypes.data, nq, k, 1 if normalize else 0,
+                                                        bits.ctypes.data if bits is not None else None,
+                                                        D.ctypes.data, I.ctypes.data))
         return D, I
 
     def search_dev(self, q_ptr: int, nq: int, k: int, D_ptr: int, I_ptr: int, stream: int = 0,

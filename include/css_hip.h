@@ -116,6 +116,17 @@ int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int 
 int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,
                          float* D_dev, int64_t* I_dev, void* stream);
 
+/* Masked search (filter / tombstone push-down; the reference
+ * instead over-fetches 100 hits and filters them afterwards, src/storage.py:438-492):
+ * only rows whose bit is set in allow_bits -- bit (r & 31) of word r >> 5, local row
+ * numbering, ceil(ntotal / 32) words -- can be returned; NULL = all rows.  Fewer than
+ * k allowed rows: padded like css_index_search. */
+int css_index_search_masked(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
+                            const uint32_t* allow_bits_host, float* D_host, int64_t* I_host);
+int css_index_search_masked_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,
+                                const uint32_t* allow_bits_dev, float* D_dev, int64_t* I_dev,
+                                void* stream);
+
 /* Merge `nparts` per-shard results ([nparts, nq, k] each) into the global
  * top-k by (score, id); used after the RCCL all-gather of per-shard top-k. */
 int css_merge_topk_dev(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts,

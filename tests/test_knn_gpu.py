@@ -308,6 +308,54 @@ def test_coarse_and_split_paths_agree(monkeypatch):
     ix.close()
 
 
+# ---- masked search (filter / tombstone push-down): every kernel family, both search modes ----------
+@pytest.mark.parametrize("metric,nq,density", [(0, 1, 0.05), (0, 3, 0.5), (0, 40, 0.05), (0, 300, 0.3),
+                                               (1, 2, 0.2), (1, 40, 0.2)])
+def test_masked_search_matches_oracle_on_the_allowed_rows(metric, nq, density):
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    n, d, k = 30000, 768, 10
+    x = synth.rows(n, d, 61)
+    q = synth.rows(nq, d, 62)
+    allow = np.random.default_rng(5).random(n) < density
+    norm = metric == 0
+    ix = IndexFlat(d, metric)
+    ix.add(x, normalize=norm)
+    sub = np.flatnonzero(allow)
+    ref = ko.FlatIndexOracle(d, metric)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if norm else (x, q)
+    ref.add(xr[sub])
+    Dr, Ir = ref.search(qr, k)
+    D64 = ref.rescore64(qr, Ir)
+    Ir = sub[Ir]
+    for mode in ("exact_fp32", "auto"):
+        ix.set_search_mode(mode)
+        D, I = ix.search(q, k, normalize=norm, allow=allow)
+        assert allow[I].all()
+        assert_topk_matches(D, I, Dr, Ir, D64, f"masked [{mode}] metric={metric} nq={nq}")
+    ix.close()
+
+
+def test_masked_search_with_few_or_no_allowed_rows_pads():
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    x = synth.rows(5000, 768, 63)
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=True)
+    allow = np.zeros(5000, dtype=bool)
+    allow[[7, 4000, 4999]] = True
+    for nq in (1, 20):
+        D, I = ix.search(x[:nq], 5, normalize=True, allow=allow)
+        assert (np.sort(I[:, :3], axis=1) == np.array([7, 4000, 4999])).all() and (I[:, 3:] == -1).all()
+        assert (D[:, 3:] == np.finfo(np.float32).min).all()
+        D, I = ix.search(x[:nq], 5, normalize=True, allow=np.zeros(5000, dtype=bool))
+        assert (I == -1).all()
+    with pytest.raises(ValueError):
+        ix.search(x[:1], 5, allow=np.zeros(10, dtype=bool))
+    ix.close()
+
+
 def test_invalid_arguments_raise():
     from claude_semantic_search_amd.flat_index import IndexFlatIP
 

@@ -32,6 +32,9 @@ def _as_f32_2d(x, d: int, what: str) -> np.ndarray:
     return a
 
 
+MAX_K = nat.MAX_K
+
+
 def pack_allow_bits(allow, ntotal: int) -> np.ndarray:
     """Boolean row mask -> the uint32 bitmap of ``css_index_search_masked`` (bit r & 31 of word r >> 5)."""
     m = np.asarray(allow)

@@ -19,7 +19,9 @@ Deliberate differences (all on the host side of the kernel):
   * a lock serialises index/id-map mutation against searches (the reference has none);
   * ``auto_save`` appends the new rows to ``embeddings.faiss`` instead of
     rewriting the whole file after every add (the reference's O(N^2) I/O);
-  * there is no CPU index: without a HIP device ``initialize()`` raises.
+  * there is no CPU index: without a HIP device ``initialize()`` raises;
+  * opt-in ``StorageConfig.filter_pushdown``: filters / tombstones become an allow-bitmap consumed by the
+    kernel (``css_index_search_masked``) instead of an over-fetch of ``max_results`` hits.
 """
 from __future__ import annotations
 
@@ -56,6 +58,10 @@ class StorageConfig:
     use_gpu: bool = False
     gpu_memory_fraction: float = 0.8
     device: int = 0  # HIP device ordinal holding the index (extension)
+    # extension: push filters and tombstones down into the kNN kernel as an allow-bitmap, so a
+    # filtered search returns the true filtered top_k instead of whatever survives inside the first
+    # ``max_results`` unfiltered hits.  Off by default: the reference's over-fetch semantics are kept bit for bit.
+    filter_pushdown: bool = False
 
 
 @dataclass
@@ -123,6 +129,7 @@ class HybridStorage:
         self._is_gpu_index: bool = False
         self._lock = threading.RLock()
         self._saved_rows = -1  # rows known to be in index_path (-1: unknown)
+        self._allow_cache: Dict[str, Any] = {}  # filter key -> (id-map size, ntotal, allow mask); push-down only
 
         self.total_chunks: int = 0
         self.embedding_dim: int = self.config.embedding_dim
@@ -263,7 +270,14 @@ class HybridStorage:
                 return []
             # accepts ndarray or a plain list (tests/test_integration.py:203-204 of the reference)
             q = np.asarray(query_embedding, dtype=np.float32).reshape(1, -1)
-            sims, ids = self.faiss_index.search(q, k, normalize=self.config.normalize_embeddings)
+            allow = None
+            if self.config.filter_pushdown and (filters or len(self.faiss_id_to_chunk_id) < ntotal):
+                allow = self._allow_mask(filters or {}, ntotal)
+                k = max(1, min(k, cfg.top_k, fi.MAX_K))
+            if allow is not None:
+                sims, ids = self.faiss_index.search(q, k, normalize=self.config.normalize_embeddings, allow=allow)
+            else:
+                sims, ids = self.faiss_index.search(q, k, normalize=self.config.normalize_embeddings)
             out: List[SearchResult] = []
             for score, fid in zip(sims[0].tolist(), ids[0].tolist()):
                 if score < cfg.similarity_threshold:
@@ -289,6 +303,29 @@ class HybridStorage:
                 if len(out) >= cfg.top_k:
                     break
             return out
+
+    def _allow_mask(self, filters: Dict[str, Any], ntotal: int) -> np.ndarray:
+        """Boolean mask over index rows: live (not tombstoned) and matching ``filters`` under exactly the
+        semantics of ``_matches_filters``.  One pass over the chunks table, cached until the id maps change."""
+        key = json.dumps(filters, sort_keys=True, default=str)
+        hit = self._allow_cache.get(key)
+        stamp = (len(self.faiss_id_to_chunk_id), ntotal, self.total_chunks)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        allow = np.zeros(ntotal, dtype=bool)
+        if not self.db:
+            raise RuntimeError("Database not initialized")
+        for row in self.db.cursor().execute("SELECT * FROM chunks"):
+            fid = self.chunk_id_to_faiss_id.get(row["id"])
+            if fid is None or fid >= ntotal or self.faiss_id_to_chunk_id.get(fid) != row["id"]:
+                continue
+            if filters and not self._matches_filters({k_: row[k_] for k_ in row.keys()}, filters):
+                continue
+            allow[fid] = True
+        if len(self._allow_cache) >= 8:
+            self._allow_cache.clear()
+        self._allow_cache[key] = (stamp, allow)
+        return allow
 
     def _get_chunk_data(self, chunk_id: str) -> Optional[Dict[str, Any]]:
         if not self.db:

@@ -270,6 +270,40 @@ class StorageCases:
         assert len(s.search(q, SearchConfig(top_k=2), {"project_name": "SEMANTIC"})) == 2
         s.close()
 
+    # SURVEY 8f rank 2 (extension, opt-in): filters / tombstones pushed down into the kernel as an allow-bitmap.
+    # 300 chunks, the 6 chunks of project "rare" are the WORST matches of the query: the reference's over-fetch of
+    # max_results=100 unfiltered hits never sees them (``src/storage.py:429-492``), the push-down returns them.
+    def test_filter_pushdown_returns_true_filtered_topk(self):
+        rng = np.random.default_rng(3)
+        q = rng.standard_normal(768).astype(np.float32)
+        chunks = []
+        for i in range(300):
+            v = rng.standard_normal(768).astype(np.float32)
+            rare = i % 50 == 7
+            v = v + (-3.0 if rare else 1.5) * q        # rare rows point away from the query
+            chunks.append(Chunk(f"c{i}", f"text {i}", {"project_name": "rare" if rare else "common", "session_id": f"s{i}",
+                                                       "message_count": i}, v.tolist()))
+        results = {}
+        for pushdown in (False, True):
+            cfg = StorageConfig(data_dir=self.tmp, embedding_dim=768, auto_save=False, db_name=f"pd{int(pushdown)}.db",
+                                index_name=f"pd{int(pushdown)}.faiss", filter_pushdown=pushdown)
+            s = HybridStorage(cfg)
+            s.initialize()
+            s.add_chunks(chunks)
+            sc = SearchConfig(top_k=5, similarity_threshold=-1.0)
+            results[pushdown] = [r.chunk_id for r in s.search(q, sc, {"project_name": "rare"})]
+            # unfiltered and satisfiable searches are identical in both modes
+            assert [r.chunk_id for r in s.search(q, sc)] == [r.chunk_id for r in s.search(q, sc, {"project_name": "common"})]
+            if pushdown:
+                rng_ids = [r.chunk_id for r in s.search(q, sc, {"message_count": {"gte": 100, "lt": 110}})]
+                assert len(rng_ids) == 5 and all(100 <= int(c[1:]) < 110 for c in rng_ids)
+                assert s.delete_chunk(results[True][0])            # tombstone: never returned again, slot not wasted
+                again = [r.chunk_id for r in s.search(q, sc, {"project_name": "rare"})]
+                assert results[True][0] not in again and len(again) == 5
+            s.close()
+        assert results[False] == []                                # starved inside the first 100 unfiltered hits
+        assert len(results[True]) == 5 and all(int(c[1:]) % 50 == 7 for c in results[True])
+
     def test_context_manager(self):
         with HybridStorage(self.config) as s:
             s.add_chunks(self.chunks)

@@ -20,9 +20,18 @@ class _FakeIndex:
         x = np.asarray(x, np.float32).reshape(-1, self.d)
         self._o.add(ko.normalize_rows(x) if normalize else x)
 
-    def search(self, q, k, normalize=False):
+    def search(self, q, k, normalize=False, allow=None):
         q = np.asarray(q, np.float32).reshape(-1, self.d)
-        return self._o.search(ko.normalize_rows(q) if normalize else q, k)
+        q = ko.normalize_rows(q) if normalize else q
+        if allow is None:
+            return self._o.search(q, k)
+        # masked search = the oracle over the allowed rows only, ids mapped back
+        sub = np.flatnonzero(np.asarray(allow, dtype=bool))
+        o = ko.FlatIndexOracle(self.d, self.metric_type)
+        if sub.size:
+            o.add(self._o._xb[sub])
+        D, I = o.search(q, k)
+        return D, np.where(I >= 0, sub[np.clip(I, 0, max(sub.size - 1, 0))] if sub.size else -1, -1)
 
     def reconstruct_n(self, row0=0, n=None):
         n = self.ntotal - row0 if n is None else n

@@ -437,6 +437,25 @@ def main():
                                    "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
             nat.prof_reset()
 
+        # ---- extra: masked search (filter / tombstone push-down), half of the rows allowed ----
+        words = (shard + 31) // 32
+        mbits = torch.full((words,), 0x55555555, dtype=torch.int32, device=dev)   # every other row
+        mk = {}
+        for nqm, reps in ((1, 10), (args.nq, 3)):
+            for _ in range(2):
+                index.search_dev(q.data_ptr(), nqm, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True,
+                                 allow_bits_ptr=mbits.data_ptr())
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                index.search_dev(q.data_ptr(), nqm, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True,
+                                 allow_bits_ptr=mbits.data_ptr())
+            fence()
+            dt = (time.perf_counter() - t0) / reps
+            assert bool((I[:nqm] % 2 == 0).all())
+            mk[f"nq{nqm}_k{args.k}"] = {"ms": dt * 1e3, "queries_per_s": nqm / dt}
+        extra["masked_half_rows"] = mk
+
         # ---- extra: the parity mode (every score formed in fp32 by the scan kernels) on the same index ----
         index.set_search_mode("exact_fp32")
         try:

@@ -124,12 +124,15 @@ class IndexFlat:
         return D, I
 
     def search_dev(self, q_ptr: int, nq: int, k: int, D_ptr: int, I_ptr: int, stream: int = 0,
-                   normalize: bool = False) -> None:
+                   normalize: bool = False, allow_bits_ptr: int = 0) -> None:
         """Device-pointer twin: ``q_ptr``/``D_ptr``/``I_ptr`` are device addresses
-        (e.g. ``tensor.data_ptr()``), enqueued on ``stream`` (a ``hipStream_t``)."""
-        nat.check(nat.lib().css_index_search_dev(self._handle(), ctypes.c_void_p(q_ptr), int(nq), int(k),
-                                                 1 if normalize else 0, ctypes.c_void_p(D_ptr),
-                                                 ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
+        (e.g. ``tensor.data_ptr()``), enqueued on ``stream`` (a ``hipStream_t``).
+        ``allow_bits_ptr``: optional device bitmap (``pack_allow_bits`` layout) of a masked search."""
+        nat.check(nat.lib().css_index_search_masked_dev(self._handle(), ctypes.c_void_p(q_ptr), int(nq), int(k),
+                                                        1 if normalize else 0,
+                                                        ctypes.c_void_p(allow_bits_ptr) if allow_bits_ptr else None,
+                                                        ctypes.c_void_p(D_ptr), ctypes.c_void_p(I_ptr),
+                                                        ctypes.c_void_p(stream)))
 
     def set_search_mode(self, mode: str) -> None:
         """``"auto"`` (default: bf16 candidate scan + exact fp32 rescoring when the index keeps

@@ -227,6 +227,51 @@ def bench_encoder(args, dev, log):
                          "total_tokens": Tm, "achieved_TFLOPs": fl2 / dt2 / 1e12,
                          "frac_of_bf16_peak": fl2 / dt2 / 1e12 / BF16_MFMA_PEAK_TF}
     log(f"encoder length mix: mean {lens.mean():.0f} tokens -> {B / dt2:.0f} chunks/s, {fl2 / dt2 / 1e12:.0f} TFLOP/s")
+
+    # ---- text path: strings -> C++ WordPiece tokenizer (host threads) -> encoder, tokenisation of the next
+    # super-batch overlapped with the GPU (MpnetEncoder.encode); synthetic vocabulary and texts (no real
+    # vocabulary exists offline), chunk lengths ~ U[100, 2000] characters as in the length-mix run
+    try:
+        import random
+        import string
+        import tempfile
+
+        from claude_semantic_search_amd.tokenizer import make_wordpiece
+
+        rng = random.Random(5)
+        words = ["".join(rng.choice(string.ascii_lowercase) for _ in range(rng.randint(2, 9))) for _ in range(8000)]
+        vocab = ["<s>", "<pad>", "</s>", "<unk>", "[UNK]"] + words + list(string.ascii_lowercase) + \
+                ["##" + c for c in string.ascii_lowercase] + list(string.punctuation) + list(string.digits)
+        vdir = tempfile.mkdtemp()
+        with open(os.path.join(vdir, "vocab.txt"), "w") as f:
+            f.write("\n".join(dict.fromkeys(vocab)) + "\n")
+        enc.tokenizer = make_wordpiece(os.path.join(vdir, "vocab.txt"))
+        ntext = 4096
+        texts = []
+        for _ in range(ntext):
+            target = rng.randint(100, 2000)
+            parts, n = [], 0
+            while n < target:
+                w = rng.choice(words)
+                parts.append(w)
+                n += len(w) + 1
+            texts.append(" ".join(parts) + ".")
+        enc.encode(texts[:512], batch_size=B)
+        t0 = time.perf_counter()
+        toks = enc.tokenize(texts)
+        t_tok = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        emb = enc.encode(texts, batch_size=B)
+        t_all = time.perf_counter() - t0
+        assert emb.shape == (ntext, 768)
+        res["text_path"] = {"chunks_per_s": ntext / t_all, "texts": ntext, "mean_chars": sum(map(len, texts)) / ntext,
+                            "mean_tokens": float(sum(len(t) for t in toks) / ntext),
+                            "tokenizer": type(enc.tokenizer).__name__, "tokenize_only_ms_per_256": t_tok / ntext * 256 * 1e3,
+                            "host_threads": os.cpu_count(), "includes": "utf-8 encode, tokenise, H2D ids, forward, D2H"}
+        log(f"encoder text path: {ntext / t_all:.0f} chunks/s end to end ({type(enc.tokenizer).__name__}, "
+            f"{t_tok / ntext * 256 * 1e3:.1f} ms tokenisation per 256 texts)")
+    except Exception as ex:  # the text path is an extra: never fail the bench line over it
+        res["text_path"] = {"error": repr(ex)}
     enc.close()
     return res
 

@@ -102,6 +102,10 @@ PROTOTYPES = {
     "css_encoder_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "css_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "css_mpnet_rel_bucket": (c_int, [c_int, c_int, c_int]),
+    "css_tokenizer_create": (c_int, [c_char_p, c_int, POINTER(c_void_p)]),
+    "css_tokenizer_free": (c_int, [c_void_p]),
+    "css_tokenizer_vocab_size": (c_int, [c_void_p, POINTER(c_int)]),
+    "css_tokenizer_encode_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int]),
     "css_prof_enable": (c_int, [c_int]),
     "css_prof_reset": (c_int, []),
     "css_prof_read": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),

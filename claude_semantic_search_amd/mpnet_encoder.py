@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence, Union
 import numpy as np
 
 from . import _native as nat
-from .tokenizer import HashTokenizer, WordPieceTokenizer
+from .tokenizer import HashTokenizer, WordPieceTokenizer, make_wordpiece  # noqa: F401
 
 DEFAULT_CFG = dict(num_layers=12, hidden=768, heads=12, ffn=3072, vocab=30527, max_pos=514, rel_buckets=32,
                    pad_id=1, max_seq_len=384, ln_eps=1e-5)
@@ -99,7 +99,7 @@ class MpnetEncoder:
             self.load_state_dict(_load_state_dict(model_dir))
             root = model_dir / "0_Transformer" if (model_dir / "0_Transformer").is_dir() else model_dir
             vocab = root / "vocab.txt"
-            self.tokenizer = WordPieceTokenizer(str(vocab)) if vocab.exists() else HashTokenizer(cfg["vocab"])
+            self.tokenizer = make_wordpiece(str(vocab)) if vocab.exists() else HashTokenizer(cfg["vocab"])
 
     # -- lifetime -----------------------------------------------------------
     def close(self) -> None:
@@ -149,6 +149,8 @@ class MpnetEncoder:
 
     def tokenize(self, texts: Sequence[str]) -> List[List[int]]:
         L = min(int(self.max_seq_length), int(self.cfg["max_seq_len"]))
+        if hasattr(self.tokenizer, "encode_batch"):
+            return self.tokenizer.encode_batch(texts, L)
         return [self.tokenizer.encode(t, L) for t in texts]
 
     def encode_ids(self, batch: Sequence[Sequence[int]], normalize: bool = True) -> np.ndarray:
@@ -157,7 +159,8 @@ class MpnetEncoder:
         lens = np.fromiter((len(s) for s in batch), dtype=np.int32, count=B)
         cu = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(lens, out=cu[1:])
-        ids = np.fromiter((t for s in batch for t in s), dtype=np.int32, count=int(cu[-1]))
+        ids = np.concatenate([np.asarray(s, dtype=np.int32) for s in batch]) if B else np.zeros(0, np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
         out = np.empty((B, self.cfg["hidden"]), dtype=np.float32)
         nat.check(nat.lib().css_encoder_forward(self._h, ids.ctypes.data, cu.ctypes.data, B, 1 if normalize else 0,
                                                 out.ctypes.data))
@@ -169,19 +172,42 @@ class MpnetEncoder:
         texts = [sentences] if single else list(sentences)
         if not texts:
             return np.zeros((0, self.cfg["hidden"]), dtype=np.float32)
-        toks = self.tokenize(texts)
-        order = sorted(range(len(toks)), key=lambda i: -len(toks[i]))
-        out = np.empty((len(toks), self.cfg["hidden"]), dtype=np.float32)
-        rng = range(0, len(order), max(1, int(batch_size)))
+        out = np.empty((len(texts), self.cfg["hidden"]), dtype=np.float32)
+        bs = max(1, int(batch_size))
+        # Super-batches of 16 device batches: the next one is tokenised on a host thread (both the C++ tokenizer and
+        # the forward release the GIL) while the GPU encodes the current one; texts are length-sorted inside a
+        # super-batch (packed var-len batches have no padding, sorting only keeps a batch's attention tiles even).
+        span = max(16 * bs, 1024)
+        starts = list(range(0, len(texts), span))
+        bar = None
         if show_progress_bar:
             try:
                 from tqdm import tqdm
 
-                rng = tqdm(rng, desc="Batches")
+                bar = tqdm(total=(len(texts) + bs - 1) // bs, desc="Batches")
             except Exception:
-                pass
-        for s in rng:
-            idx = order[s:s + batch_size]
-            # Normalize() is a module of the model: outputs are unit norm regardless of the flag
-            out[idx] = self.encode_ids([toks[i] for i in idx], normalize=True)
+                bar = None
+        def run(base: int, toks) -> None:
+            order = sorted(range(len(toks)), key=lambda i: -len(toks[i]))
+            for s in range(0, len(order), bs):
+                idx = order[s:s + bs]
+                # Normalize() is a module of the model: outputs are unit norm regardless of the flag
+                out[[base + i for i in idx]] = self.encode_ids([toks[i] for i in idx], normalize=True)
+                if bar is not None:
+                    bar.update(1)
+
+        if len(starts) == 1:  # (the single-query path: no thread hop)
+            run(0, self.tokenize(texts))
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                fut = pool.submit(self.tokenize, texts[:span])
+                for si, base in enumerate(starts):
+                    toks = fut.result()
+                    if si + 1 < len(starts):
+                        fut = pool.submit(self.tokenize, texts[starts[si + 1]:starts[si + 1] + span])
+                    run(base, toks)
+        if bar is not None:
+            bar.close()
         return out[0] if single else out

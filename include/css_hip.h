@@ -179,6 +179,21 @@ int css_encoder_debug_read(css_encoder* enc, const char* what, float* out_host, 
  * (the encoder builds its per-head Toeplitz bias table from it). */
 int css_mpnet_rel_bucket(int rel, int num_buckets, int max_distance);
 
+/* ---- WordPiece front end of encode() (host code; the tokenizer half of
+ * SentenceTransformer.encode, src/embeddings.py:184-188, :216-222) ----
+ * vocab.txt in HF layout (one piece per line, id = line number).  encode_batch:
+ * `bytes` holds the n UTF-8 texts back to back, text i = [offsets[i], offsets[i+1]);
+ * ids_out is [n, max_len] (padded with <pad>), lens_out[i] the token count incl.
+ * <s> and </s>, or -1 for a text with non-ASCII bytes, which the caller tokenises with
+ * the Unicode-complete Python implementation of the same pipeline.  nthreads <= 0: all cores. */
+typedef struct css_tokenizer css_tokenizer;
+int css_tokenizer_create(const char* vocab_path, int lowercase, css_tokenizer** out);
+int css_tokenizer_free(css_tokenizer* t);
+int css_tokenizer_vocab_size(const css_tokenizer* t, int* n);
+int css_tokenizer_encode_batch(const css_tokenizer* t, const char* bytes, const int64_t* offsets,
+                               int64_t n, int max_len, int32_t* ids_out, int32_t* lens_out,
+                               int nthreads);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) ---- */
 /* When enabled, each launch of a named dominant kernel is bracketed by HIP
  * events on the stream it is launched on; css_prof_read drains and sums them. */

@@ -44,3 +44,32 @@ def test_index_then_search_sequence():
         res = st.search(q, SearchConfig(top_k=5), {"session_id": "s0"})
         assert res and all(r.metadata["session_id"] == "s0" for r in res)
         st.close()
+
+
+def test_pipelined_encode_and_native_tokenizer_with_a_vocab_file(tmp_path):
+    """Real-text front end: a model directory in HF layout with a (synthetic) vocab.txt -> the C++ WordPiece
+    tokenizer feeds the encoder; several super-batches (tokenisation of the next one overlaps the GPU) give the
+    same embeddings as one text at a time."""
+    import json
+    import random
+    import string
+
+    from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+    from claude_semantic_search_amd.tokenizer import NativeWordPieceTokenizer, make_wordpiece
+
+    rng = random.Random(7)
+    words = ["".join(rng.choice(string.ascii_lowercase) for _ in range(rng.randint(2, 9))) for _ in range(500)]
+    vocab = ["<s>", "<pad>", "</s>", "<unk>", "[UNK]"] + words + list(string.ascii_lowercase) + \
+            ["##" + c for c in string.ascii_lowercase] + list(string.punctuation) + ["é"]
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(dict.fromkeys(vocab)) + "\n", encoding="utf-8")
+    enc = MpnetEncoder(synthetic_seed=3, cfg_overrides={"num_layers": 2})
+    enc.tokenizer = make_wordpiece(str(vp))
+    assert isinstance(enc.tokenizer, NativeWordPieceTokenizer)
+    texts = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 60))) + rng.choice(["", ".", " café!", " X=1"])
+             for _ in range(2500)]
+    out = enc.encode(texts, batch_size=64)                     # 2500 texts > one super-batch of 1024
+    assert out.shape == (2500, 768) and np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-4)
+    for i in (0, 1, 1023, 1024, 1500, 2499):
+        assert np.allclose(out[i], enc.encode(texts[i]), atol=2e-3)
+    enc.close()

@@ -1,6 +1,13 @@
-"""CPU: host-side tokenisation front end (self-made cases; parity with the real
-all-mpnet-base-v2 tokenizer is unpinned because no vocabulary exists offline)."""
-from claude_semantic_search_amd.tokenizer import BOS, EOS, HashTokenizer, WordPieceTokenizer, basic_tokenize
+"""CPU: host-side tokenisation front end.  The WordPiece pipeline is pinned against transformers'
+MPNetTokenizer (HF ``tokenizers`` backend) on a synthetic vocabulary; parity on the real all-mpnet-base-v2
+vocabulary is unpinned because no vocabulary file exists offline."""
+import random
+import string
+
+import pytest
+
+from claude_semantic_search_amd.tokenizer import (BOS, EOS, FastWordPieceTokenizer, HashTokenizer, WordPieceTokenizer,
+                                                  basic_tokenize, make_wordpiece)
 
 
 def test_basic_tokenize_lowercase_accents_punct():
@@ -8,6 +15,9 @@ def test_basic_tokenize_lowercase_accents_punct():
     assert basic_tokenize("  \t\n ") == []
     assert basic_tokenize("don't") == ["don", "'", "t"]
     assert basic_tokenize("Keep CASE", lower=False) == ["Keep", "CASE"]
+    # BERT cleaning: control / zero-width characters and U+FFFD vanish, CJK ideographs stand alone
+    assert basic_tokenize("x\u200by \x00a\ufffdb") == ["xy", "ab"]
+    assert basic_tokenize("a中文b") == ["a", "中", "文", "b"]
 
 
 def test_hash_tokenizer_shape_truncation_determinism():
@@ -30,3 +40,56 @@ def test_wordpiece_greedy_longest_match(tmp_path):
     assert t.encode("unaffable", 16) == [0, v["un"], v["##aff"], v["##able"], 2]
     assert t.encode("Pythons, the xyz", 16) == [0, v["python"], v["##s"], v[","], v["the"], v["<unk>"], 2]
     assert t.encode("the " * 50, 8) == [0] + [v["the"]] * 6 + [2]
+
+
+def _synthetic_vocab(tmp_path, rng):
+    words = ["".join(rng.choice(string.ascii_lowercase) for _ in range(rng.randint(1, 8))) for _ in range(800)]
+    pieces = ["<s>", "<pad>", "</s>", "<unk>", "[UNK]", "<mask>"] + sorted(set(words))
+    pieces += ["##" + "".join(rng.choice(string.ascii_lowercase) for _ in range(rng.randint(1, 3))) for _ in range(600)]
+    pieces += list(string.punctuation) + list(string.digits) + ["##" + d for d in string.digits]
+    pieces += ["é", "中", "##中", "ü", "naive", "cafe", "…", "“", "ss", "i"]
+    pieces = list(dict.fromkeys(pieces))
+    p = tmp_path / "vocab.txt"
+    p.write_text("\n".join(pieces) + "\n", encoding="utf-8")
+    return str(p), words
+
+
+def _random_text(rng, words):
+    parts = []
+    for _ in range(rng.randint(1, 40)):
+        r = rng.random()
+        if r < 0.6:
+            parts.append(rng.choice(words))
+        elif r < 0.7:
+            parts.append(rng.choice(words).upper())
+        elif r < 0.8:
+            parts.append(rng.choice(words) + rng.choice(words))
+        elif r < 0.85:
+            parts.append(rng.choice(["café", "naïve", "Ünï", "中文字", "a中b", "…", "“q”", "x\u200by", "tab\there",
+                                     "\x00nul", "ＡＢ", "ß", "İ", "\ufffd", "a\u00adb", "x" * 120]))
+        elif r < 0.95:
+            parts.append(rng.choice(string.punctuation) + rng.choice(words))
+        else:
+            parts.append(str(rng.randint(0, 99999)))
+    return rng.choice([" ", "  ", "\n"]).join(parts)
+
+
+def test_wordpiece_pipeline_matches_transformers_mpnet_tokenizer(tmp_path):
+    mpnet = pytest.importorskip("transformers.models.mpnet.tokenization_mpnet")
+    rng = random.Random(1)
+    vocab_path, words = _synthetic_vocab(tmp_path, rng)
+    mine = WordPieceTokenizer(vocab_path)
+    fast = make_wordpiece(vocab_path)
+    hf = mpnet.MPNetTokenizer(vocab=dict(mine.vocab))
+    texts = [_random_text(rng, words) for _ in range(600)] + ["", " ", "word " * 500]
+    want = [hf(t, truncation=True, max_length=64)["input_ids"] for t in texts]
+    assert [mine.encode(t, 64) for t in texts] == want
+    assert FastWordPieceTokenizer(vocab_path).encode_batch(texts, 64) == want   # HF tokenizers is part of this image
+    # the C++ front end of libcss_hip.so (ASCII texts native, the rest through the Unicode-complete path)
+    from claude_semantic_search_amd.tokenizer import NativeWordPieceTokenizer
+
+    assert isinstance(fast, NativeWordPieceTokenizer)
+    ascii_only = ["".join(ch for ch in t if ord(ch) < 128) for t in texts] + ["a\x0bb\x7fc  D.E\tf\r\ng", "x" * 101, "x" * 100]
+    got = fast.encode_batch(texts + ascii_only, 64)
+    assert [g.tolist() for g in got] == want + [hf(t, truncation=True, max_length=64)["input_ids"] for t in ascii_only]
+    assert fast.encode("Hello, World", 8) == hf("Hello, World", truncation=True, max_length=8)["input_ids"]

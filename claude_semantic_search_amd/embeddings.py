@@ -48,6 +48,10 @@ class EmbeddingConfig:
     synthetic_weights_seed: Optional[int] = None
     compute: str = "bf16"  # "bf16" (MFMA product path) or "fp32" (verification mode)
     device_index: int = 0
+    # keep ``chunk.embedding`` as a float32 ndarray row instead of the reference's Python list (src/embeddings.py:175):
+    # the list round trip (tolist here, np.array in add_chunks, src/storage.py:343) costs as much host time per 10k
+    # chunks (~0.5 s) as their whole GPU encode.  Off by default (drop-in behaviour).
+    embeddings_as_arrays: bool = False
 
 
 @dataclass
@@ -122,8 +126,12 @@ class EmbeddingGenerator:
         if not chunks:
             return []
         embeddings = self._generate_embeddings_batch([c.text for c in chunks])
-        for chunk, row in zip(chunks, embeddings):
-            chunk.embedding = row.tolist()
+        if self.config.embeddings_as_arrays:
+            for chunk, row in zip(chunks, embeddings):
+                chunk.embedding = row
+        else:
+            for chunk, row in zip(chunks, embeddings):
+                chunk.embedding = row.tolist()
         return embeddings
 
     def generate_single_embedding(self, text: str) -> np.ndarray:

@@ -223,7 +223,10 @@ class HybridStorage:
         if not with_emb:
             self.logger.warning("No chunks with embeddings to add")
             return
-        x = np.array([c.embedding for c in with_emb], dtype=np.float32)
+        if all(isinstance(c.embedding, np.ndarray) for c in with_emb):
+            x = np.stack([c.embedding for c in with_emb]).astype(np.float32, copy=False)  # EmbeddingConfig.embeddings_as_arrays
+        else:
+            x = np.array([c.embedding for c in with_emb], dtype=np.float32)
         if not self.faiss_index:
             raise RuntimeError("FAISS index not initialized")
         if not self.db:

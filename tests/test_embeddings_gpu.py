@@ -46,6 +46,21 @@ def test_index_then_search_sequence():
         st.close()
 
 
+def test_embeddings_as_arrays_skips_the_list_round_trip():
+    texts = [f"chunk number {i} about topic {i % 7}" for i in range(40)]
+    outs = {}
+    for as_arrays in (False, True):
+        g = EmbeddingGenerator(EmbeddingConfig(use_gpu=True, show_progress=False, synthetic_weights_seed=1,
+                                               embeddings_as_arrays=as_arrays))
+        chunks = [Chunk(f"c{i}", t, {"session_id": "s"}) for i, t in enumerate(texts)]
+        g.generate_embeddings(chunks)
+        assert isinstance(chunks[0].embedding, np.ndarray if as_arrays else list) and len(chunks[0].embedding) == 768
+        with HybridStorage(StorageConfig(data_dir=tempfile.mkdtemp(), auto_save=False)) as s:
+            s.add_chunks(chunks)
+            outs[as_arrays] = [(r.chunk_id, round(r.similarity, 5)) for r in s.search(g.generate_single_embedding(texts[3]), SearchConfig(top_k=5))]
+    assert outs[False] == outs[True] and outs[True][0][0] == "c3"
+
+
 def test_pipelined_encode_and_native_tokenizer_with_a_vocab_file(tmp_path):
     """Real-text front end: a model directory in HF layout with a (synthetic) vocab.txt -> the C++ WordPiece
     tokenizer feeds the encoder; several super-batches (tokenisation of the next one overlaps the GPU) give the

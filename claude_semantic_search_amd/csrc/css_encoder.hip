@@ -241,14 +241,13 @@ int ensure_acts(css_encoder* e, int T, int B) {
 }
 
 extern int g_gemm_dbg;
-extern int g_gemm_ring;
 // Tile shapes: 2x2 waves x (2x2) MFMA tiles = 128x128, or 2x4 waves x (4x2) tiles = 256x256
 // (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
 template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB, int SPS>
 int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   float qscale, int num_cus, hipStream_t st, const char* prof) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    CSS_REQUIRE(N % BN == 0 && K % 64 == 0 && K / 64 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 32 (>= 96)", N, BN, K);
+    CSS_REQUIRE(N % BN == 0 && K % 64 == 0 && K / 64 >= 3, "gemm: N=%d must be a multiple of %d and K=%d of 64 (>= 192)", N, BN, K);
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
     auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB, SPS>;
     const size_t lds = (size_t)NST * (BM + BN) * RB;  // ring of NST stages, RB bytes of K per row
@@ -270,7 +269,7 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
 int g_enc_resid = 2;       // CSS_ENC_RESID: residual stream storage in bf16 mode (see forward_typed)
 int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
 int g_gemm_big_tiles = 1;
-int g_gemm_ring = 2;       // CSS_GEMM_RING: 2 = 2 stages x 128 B rows (default: fewest barriers, measured fastest), 3 = 3 x 64 B, 4 = 4 x 64 B  // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
+// CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
 
 template <typename TIn, int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
@@ -287,11 +286,9 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M,
         return CSS_OK;
     }
     if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
-        // ring shape: 4 x 64 KiB... (NST stages x RB bytes of K per row); CSS_GEMM_RING selects for A/B runs
-        if (g_gemm_ring == 2) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
-        if (g_gemm_ring == 5) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 5, 64, 2>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
-        if (g_gemm_ring == 3) return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 3, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
-        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 4, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
+        // ring: 2 stages x 128 B rows.  Rings of 3 / 4 x 64 B rows and 5 x 64 B with two stages per step were
+        // measured slower (more barriers, same LDS fill rate) and are not kept.
+        return launch_gemm_t<TIn, EPI, 2, 4, 4, 2, 2, 128, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
     }
     return launch_gemm_t<TIn, EPI, 2, 2, 2, 2, 4, 64, 1>(A, W, bias, C, M, N, K, qscale_cols, qscale, num_cus, st, prof);
 }
@@ -408,7 +405,6 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     DeviceGuard g(device);
     if (const char* t = getenv("CSS_GEMM_TILE")) g_gemm_big_tiles = atoi(t) != 128;
     if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
-    if (const char* t = getenv("CSS_GEMM_RING")) g_gemm_ring = atoi(t);
     if (const char* t = getenv("CSS_ENC_RESID")) g_enc_resid = atoi(t);
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;

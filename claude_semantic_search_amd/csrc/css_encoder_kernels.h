@@ -230,15 +230,23 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
     constexpr int PIECES = (BM + BN) / RPP;    // 1-KiB LDS-DMA pieces per stage
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
     constexpr int PPW = PIECES / NW;        // LDS-DMA instructions per wave per stage
-    constexpr int E = TM * TN * 4;          // store instructions per wave per tile
+    constexpr bool OUT16 = BF && EPI == EPI_QKV;  // these bf16 outputs leave as 16-B stores (2 per 32x32 block)
+    constexpr int E = TM * TN * (OUT16 ? 2 : 4);  // store instructions per wave per tile (vmcnt bookkeeping)
     // SPS ring stages are consumed per barrier step; Y stages stay in flight across a step's wait
     constexpr int Y = NST - 2 * SPS;
     static_assert(Y >= 0 && Y <= 2 && (SPS == 1 || SPS == 2), "ring shape");
     static_assert(Y * PPW + E <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST][A_BYTES | B_BYTES]
+    // The tile's BN bias values travel global -> registers of wave 0 (second step of the tile) -> this static
+    // LDS array (third step) -> 16-B epilogue reads.  (256 scalar loads per tile, each pinned and waited for, used
+    // to cost 8-15 us per tile: more than a third of a K = 768 tile; a copy inside the dynamic ring made hipcc
+    // drain the DMA queue before reading it, a separate LDS object does not alias the ring.)
+    __shared__ __attribute__((aligned(16))) float sbias[BN];
+    static_assert(BN <= 256, "one wave stages the bias row of a tile");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
+    float4 bias_regs = make_float4(0.f, 0.f, 0.f, 0.f);
     const int fr = lane & 31, fh = lane >> 5;
 
     // XCD-aware persistent tile walk: XCD x (blocks with blockIdx % 8 == x under round-robin
@@ -319,7 +327,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
         } else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Y >= 2 ? 2 : 0) * PPW) : "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((Y >= 1 ? 1 : 0) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0 && kt == 2 * SPS) {  // bias row of this tile -> LDS (visible after this step's barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < BN / 4) *reinterpret_cast<float4*>(&sbias[4 * lane]) = bias_regs;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();  // all pieces of this step's stages landed; the previous step's slots are free
+        if (wave == 0 && kt == SPS && lane < BN / 4) {
+            const int tile_b = xfirst + jx + ct_tile * per_x;
+            bias_regs = *reinterpret_cast<const float4*>(bias + (tile_b % ntn) * BN + 4 * lane);
+        }
 #pragma unroll
         for (int u = 0; u < SPS; ++u)
             if (gi < total) {
@@ -374,33 +391,18 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
             // output columns 8*g4 + 4*fh + {0..3} of each 32-column tile.
             const int tile = xfirst + jx + ct_tile * per_x;
             const int row0 = (tile / ntn) * BM, col0 = (tile % ntn) * BN;
-            // bias through the SCALAR path (wave-uniform address, s_load, lgkmcnt): an LDS copy
-            // of the bias made hipcc drain the LDS-DMA ring (vmcnt(0)) before reading it, and
-            // a vector load would sit on the counted vmcnt queue.
-            const int cuni = col0 + wc * (TN * 32);  // wave-uniform
-            const int cbase = cuni + 4 * fh;
+            const int cbase = col0 + wc * (TN * 32) + 4 * fh;
             if (!(dbg & 1)) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m) {
                     const size_t rbase = (size_t)(row0 + wr * (TM * 32) + 32 * m + fr) * N + cbase;  // may be a slack row
 #pragma unroll
                     for (int n = 0; n < TN; ++n) {
+                        uint2 packed[4];  // bf16 outputs: 4 columns per register group, packed 2 per dword
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const int col = cbase + 32 * n + 8 * g4;
-                            const float* bp = bias + cuni + 32 * n + 8 * g4;  // uniform -> scalar loads
-                            float b8[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                float t = bp[j];
-                                asm volatile("" : "+s"(t));  // pin to an SGPR: keeps the load on the scalar path
-                                b8[j] = t;
-                            }
-                            float4 bv;
-                            bv.x = fh ? b8[4] : b8[0];
-                            bv.y = fh ? b8[5] : b8[1];
-                            bv.z = fh ? b8[6] : b8[2];
-                            bv.w = fh ? b8[7] : b8[3];
+                            const float4 bv = *reinterpret_cast<const float4*>(&sbias[wc * (TN * 32) + 32 * n + 8 * g4 + 4 * fh]);
                             float4 v;
                             v.x = acc[m][n][4 * g4 + 0] + bv.x;
                             v.y = acc[m][n][4 * g4 + 1] + bv.y;
@@ -419,10 +421,30 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
                             }
                             if constexpr (EPI == EPI_RESID || !BF) {
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cout) + rbase + 32 * n + 8 * g4) = v;
+                            } else if constexpr (OUT16) {
+                                packed[g4].x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                                packed[g4].y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
                             } else {
                                 ushort4 h;
                                 h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
                                 *reinterpret_cast<ushort4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + 32 * n + 8 * g4) = h;
+                            }
+                        }
+                        if constexpr (OUT16) {
+                            // A lane holds columns 8 g4 + 4 fh + {0..3}; its partner (lane ^ 32) the other half of each
+                            // 8-column group.  Swap halves so that every lane stores 16 B (8 consecutive bf16): row-per-
+                            // lane 8-B stores are store-issue bound (MI355X_MICROARCH.md), 16-B stores halve the count.
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                // (v_permlane32_swap_b32 does this exchange without the LDS crossbar; measured 1 % slower)
+                                const uint2 mine_a = packed[2 * j], mine_b = packed[2 * j + 1];
+                                const uint2 send = fh ? mine_a : mine_b;
+                                uint2 recv;
+                                recv.x = (unsigned)__shfl_xor((int)send.x, 32);
+                                recv.y = (unsigned)__shfl_xor((int)send.y, 32);
+                                // fh = 0 stores columns 16 j + 0..7 of the 32-column tile, fh = 1 columns 16 j + 8..15
+                                const uint4 o = fh ? make_uint4(recv.x, recv.y, mine_b.x, mine_b.y) : make_uint4(mine_a.x, mine_a.y, recv.x, recv.y);
+                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cout) + rbase - 4 * fh + 32 * n + 16 * j + 8 * fh) = o;
                             }
                         }
                     }

@@ -35,6 +35,7 @@
 #include <cmath>
 #include <mutex>
 #include <shared_mutex>
+#include <type_traits>
 #include <vector>
 
 using namespace css;
@@ -1307,9 +1308,18 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         g_knn_dbg = m ? atoi(m) : 0;
     }
     // (the DBG instantiations honour CSS_KNN_DBG; the product kernels carry no timing switches)
+    // v_mfma_f32_16x16x32_bf16 by default: same cycles per flop and LDS traffic as 32x32x16, but the chip holds a
+    // higher clock under it (measured in one session: main stage 11.1 ms vs 12.1 ms); CSS_KNN_MFMA=32 for A/B runs
+    static int mfma_shape = -1;
+    if (mfma_shape < 0) {
+        const char* m = getenv("CSS_KNN_MFMA");
+        mfma_shape = (m && atoi(m) == 32) ? 32 : 16;
+    }
     const scan_fn f_stage0 = k_scan_coarse<true, false>;
-    const scan_fn f_mid = g_knn_dbg ? k_scan_coarse<false, false, true> : k_scan_coarse<false, false>;
-    const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true> : k_scan_coarse<false, true>;
+    const scan_fn f_mid = g_knn_dbg ? k_scan_coarse<false, false, true>
+                                    : (mfma_shape == 16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
+    const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true>
+                                     : (mfma_shape == 16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>);
     static bool attr_set = false;
     if (!attr_set) {
         for (scan_fn f : {f_stage0, f_mid, f_main})

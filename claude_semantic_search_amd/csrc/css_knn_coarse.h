@@ -61,21 +61,25 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
 // allow-bitmap test of a masked search (filter / tombstone push-down): bit r&31 of word r>>5
 #define CZ_ALLOWED(MASK_, ROW_) ((MASK_) == nullptr || (((MASK_)[(ROW_) >> 5] >> ((ROW_) & 31)) & 1u))
 
-// Epilogue of one 256x256 tile of k_scan_coarse (uses the kernel's locals).
+// Epilogue of one 256x256 tile of k_scan_coarse (uses the kernel's locals).  Accumulator geometry by MFMA shape MS:
+//   32x32x16: lane (lq = lane & 31, lg = lane >> 5): query 32 m + lq, register r = row (r&3) + 8 (r>>2) + 4 lg of row tile n
+//   16x16x32: lane (lq = lane & 15, lg = lane >> 4): query 16 m + lq, register r = row 4 lg + r of row tile n
+#define CZ_QOFF(M_) (MS * (M_) + lq)
+#define CZ_ROFF(N_, R_) (MS == 32 ? 32 * (N_) + ((R_) & 3) + 8 * ((R_) >> 2) + 4 * lg : 16 * (N_) + 4 * lg + (R_))
 #define CZ_EPILOGUE()                                                                                        \
             const int64_t tile = tile_of(ct_tile);                                                                     \
-            const int64_t row0 = tile * CZ_T + wc * 64 + 4 * fh;                                                       \
+            const int64_t row0 = tile * CZ_T + wc * 64;                                                                \
             if (dbg & 1) {                                                                                             \
             } else if constexpr (STAGE0) {                                                                             \
                 const int64_t u = u0 + (int64_t)ct_tile * ustep;                                                       \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
-                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + 32 * m + fr) * CZ_CAP + (size_t)u * CZ_T + wc * 64 + 4 * fh; \
+                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + CZ_QOFF(m)) * CZ_CAP + (size_t)u * CZ_T + wc * 64; \
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
-                        for (int r = 0; r < 16; ++r) {                                                                 \
-                            const int ro = 32 * n + (r & 3) + 8 * (r >> 2);                                            \
+                        for (int r = 0; r < NR; ++r) {                                                                 \
+                            const int ro = CZ_ROFF(n, r);                                                              \
                             const bool ok = row0 + ro < ntotal && CZ_ALLOWED(mask, row0 + ro);                         \
                             cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;                                           \
                             cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;                                \
@@ -88,18 +92,18 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
-                        for (int r = 0; r < 16; ++r) any |= acc[m][n][r] >= thr_m[m];                                  \
+                        for (int r = 0; r < NR; ++r) any |= acc[m][n][r] >= thr_m[m];                                  \
                 if (__ballot(any) != 0ull) {                                                                           \
 _Pragma("unroll")                                                                                                      \
                     for (int m = 0; m < TM; ++m) {                                                                     \
-                        const int q = qtile * CZ_T + wr * 128 + 32 * m + fr;                                           \
+                        const int q = qtile * CZ_T + wr * 128 + CZ_QOFF(m);                                            \
 _Pragma("unroll")                                                                                                      \
                         for (int n = 0; n < TN; ++n)                                                                   \
 _Pragma("unroll")                                                                                                      \
-                            for (int r = 0; r < 16; ++r) {                                                             \
+                            for (int r = 0; r < NR; ++r) {                                                             \
                                 const float v = acc[m][n][r];                                                          \
                                 if (v >= thr_m[m]) {                                                                   \
-                                    const int64_t row = row0 + 32 * n + (r & 3) + 8 * (r >> 2);                        \
+                                    const int64_t row = row0 + CZ_ROFF(n, r);                                          \
                                     if (row < ntotal && CZ_ALLOWED(mask, row)) {                                       \
                                         const int slot = atomicAdd(&cand_n[q], 1);                                     \
                                         if (slot < CZ_CAP) {                                                           \
@@ -117,17 +121,17 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                 for (int n = 0; n < TN; ++n)                                                                           \
 _Pragma("unroll")                                                                                                      \
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;                                                   \
+                    for (int r = 0; r < NR; ++r) acc[m][n][r] = 0.f;                                                   \
     do {} while (0)
 
 // One stage of the cascade.  Grid = one block of 8 waves per CU (persistent).  Block -> (query tile, stream of
 // row tiles): the nqt blocks that share a row tile sit on one XCD (blockIdx % 8) and walk side by side, so the
 // tile's rows are fetched from HBM once per XCD L2.
-// Wave grid 2 (query halves) x 4 (row quarters); a wave holds 4 x 2 accumulator tiles of 32x32: lane = one
-// query column per 32-query tile (4 queries per lane), 32 registers of 64 index rows each.
+// Wave grid 2 (query halves) x 4 (row quarters); a wave's 128 queries x 64 rows are 8 x 4 accumulator tiles of
+// 16x16 (MS = 16, default: a lane owns 8 query columns x 16 rows) or 4 x 2 tiles of 32x32 (MS = 32).
 // STAGE0: every score is written to slot (tile ordinal * 256 + row in tile); otherwise scores >= thr are
 // appended.  MAIN only gives the last (stride 1, 3/4 of the rows) stage its own name in profiles.
-template <bool STAGE0, bool MAIN, bool DBG = false>
+template <bool STAGE0, bool MAIN, bool DBG = false, int MS = 32>
 __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __restrict__ xh,
                                                      const unsigned short* __restrict__ qh,
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
@@ -139,14 +143,16 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
     // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads
     const int dbg = DBG ? dbg_arg : 0;
-    constexpr int NW = 8, WN = 4, TM = 4, TN = 2;
+    static_assert(MS == 32 || MS == 16, "MFMA shape: 32x32x16 or 16x16x32");
+    constexpr int NW = 8, WN = 4, TM = 128 / MS, TN = 64 / MS, NR = MS == 32 ? 16 : 4;
+    typedef typename std::conditional<MS == 32, f32x16, v4f>::type acc_t;
     constexpr int A_BYTES = CZ_T * CZ_RB;
     constexpr int PPW = (2 * CZ_T / 8) / NW;  // 1-KiB LDS-DMA pieces (8 rows) per wave per stage = 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    const int fr = lane & 31, fh = lane >> 5;
+    const int lq = MS == 32 ? (lane & 31) : (lane & 15), lg = MS == 32 ? (lane >> 5) : (lane >> 4);
 
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
     const int slots = per_x / nqt;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 
     float thr_m[TM];
 #pragma unroll
-    for (int m = 0; m < TM; ++m) thr_m[m] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + wr * 128 + 32 * m + fr];
+    for (int m = 0; m < TM; ++m) thr_m[m] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + wr * 128 + CZ_QOFF(m)];
 
     // Sibling pacing (speed only, never needed for correctness): the nqt blocks that walk the same row tiles
     // drift apart (appends, DMA jitter); once they are more than ~2 K-steps apart the tile's rows have left
@@ -208,13 +214,13 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                          (__attribute__((address_space(3))) void*)(smem + (SLOT_) * CZ_STAGE + dst[i]), 16, 0, 0); \
     }
 
-    f32x16 acc[TM][TN];
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[m][n][r] = 0.f;
 
     int it_tile = 0, it_kt = 0, gi = 0;
     set_src(0);
@@ -259,30 +265,36 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         }
         const char* Ab = smem + (g & 1) * CZ_STAGE;
         const char* Bb = Ab + A_BYTES;
+        // C_: 16-wide k step 0..3 (MS = 32: chunk 2 C_ + lg) or 32-wide k step 0..1 (MS = 16: chunk 4 C_ + lg)
 #define CZ_READ(A_, B_, C_)                                                                                            \
     _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                                    \
-        A_[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + 32 * m + fr, 2 * (C_) + fh));                    \
+        A_[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + MS * m + lq, (MS == 32 ? 2 : 4) * (C_) + lg));   \
     _Pragma("unroll") for (int n = 0; n < TN; ++n)                                                                    \
-        B_[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + 32 * n + fr, 2 * (C_) + fh));
+        B_[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + MS * n + lq, (MS == 32 ? 2 : 4) * (C_) + lg));
 #define CZ_MFMA(A_, B_)                                                                                                \
     _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                                    \
-        _Pragma("unroll") for (int n = 0; n < TN; ++n)                                                                \
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, B_[n]),                      \
-                                                                __builtin_bit_cast(v8bf, A_[m]), acc[m][n], 0, 0, 0);
+        _Pragma("unroll") for (int n = 0; n < TN; ++n) {                                                              \
+            if constexpr (MS == 32)                                                                                    \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, B_[n]),                  \
+                                                                    __builtin_bit_cast(v8bf, A_[m]), acc[m][n], 0, 0, 0); \
+            else                                                                                                       \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, B_[n]),                  \
+                                                                    __builtin_bit_cast(v8bf, A_[m]), acc[m][n], 0, 0, 0); \
+        }
         // MFMA rows <- index rows, MFMA columns <- queries: lane (fr, fh) holds query fr and index rows
         // (r&3) + 8(r>>2) + 4 fh of the 32-row tile in register r
         if constexpr (!DBG) {
             // (explicitly double-buffered fragment reads pinned with sched_barrier measured 2 % slower than
             // hipcc's own read / wait / 4-MFMA groups: LDS latency is not what bounds this loop)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < (MS == 32 ? 4 : 2); ++c) {
                 v4f a[TM], b[TN];
                 CZ_READ(a, b, c)
                 CZ_MFMA(a, b)
             }
         } else if (!(dbg & 2)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < (MS == 32 ? 4 : 2); ++c) {
                 v4f a[TM], b[TN];
                 if (!(dbg & 16)) {
                     CZ_READ(a, b, c)

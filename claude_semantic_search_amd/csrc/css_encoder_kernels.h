@@ -463,6 +463,183 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 #undef GM_ISSUE
 }
 
+// ---------------------------------------------------------------- bf16 GEMM on v_mfma_f32_16x16x32_bf16
+// The product-mode configuration of k_gemm (bf16, 256x256 tile, 2x4 waves, 2 x 64-KiB LDS-DMA ring) with the
+// 16x16x32 MFMA: same cycles per flop and the same LDS traffic as 32x32x16, but the chip holds a higher clock
+// under it (MI355X_MICROARCH.md, DVFS item 7; measured +8 % on the kNN scan's identical main loop).
+// Accumulator geometry: lane (lq = lane & 15, lg = lane >> 4) holds token row 16 m + lq (m < 8) and the 4
+// consecutive output columns 16 n + 4 lg + {0..3} (n < 4) of the wave's 128 x 64 block.
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                const float* __restrict__ bias, void* __restrict__ Cout, int M, int N,
+                                                int K, int qscale_cols, float qscale) {
+    constexpr int NW = 8, WN = 4, TM = 8, TN = 4, BM = 256, BN = 256, RB = 128;
+    constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB, PPW = 8;
+    constexpr bool OUT16 = EPI == EPI_QKV;            // 16-B bf16 stores after a half exchange with lane ^ 16
+    constexpr bool OUT32 = EPI == EPI_RESID;          // fp32 rows
+    constexpr int E = OUT16 ? TM * TN / 2 : TM * TN;  // store instructions per wave per tile
+    static_assert(E <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A_BYTES | B_BYTES]
+    __shared__ __attribute__((aligned(16))) float sbias[BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lq = lane & 15, lg = lane >> 4;
+    float4 bias_regs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
+    const int KT = K / 64;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* src[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + NW * i;
+        dst[i] = (piece < 32 ? 0 : A_BYTES) + (piece & 31) * 1024;
+    }
+    auto set_src = [&](int tile_idx) {
+        const int tile = xfirst + jx + tile_idx * per_x;
+        const int r0 = (tile / ntn) * BM, c0 = (tile % ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + NW * i;
+            const bool isA = piece < 32;
+            const int trow = (piece & 31) * 8 + prow;
+            int grow = (isA ? r0 : c0) + trow;
+            const int lim = isA ? M : N;
+            grow = grow < lim ? grow : lim - 1;
+            src[i] = reinterpret_cast<const char*>((isA ? A : W) + (size_t)grow * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);
+        }
+    };
+#define G16_ISSUE(KT_, SLOT_)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * RB), \
+                                         (__attribute__((address_space(3))) void*)(smem + (SLOT_) * STAGE + dst[i]), 16, 0, 0); \
+    }
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    int it_tile = 0, it_kt = 0, gi = 0;
+    set_src(0);
+    G16_ISSUE(0, 0)
+    gi = 1;
+    if (++it_kt == KT) {
+        it_kt = 0;
+        if (++it_tile < my_ntiles) set_src(it_tile);
+    }
+    int ct_tile = 0, kt = 0;
+    for (int g = 0; g < total; ++g) {
+        // the tile's first stage was issued before the previous tile's E epilogue stores
+        if (ct_tile > 0 && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0 && kt == 2) {  // bias row of this tile -> LDS (visible after this step's barrier)
+            *reinterpret_cast<float4*>(&sbias[4 * lane]) = bias_regs;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && kt == 1) {
+            const int tile_b = xfirst + jx + ct_tile * per_x;
+            bias_regs = *reinterpret_cast<const float4*>(bias + (tile_b % ntn) * BN + 4 * lane);
+        }
+        if (gi < total) {
+            G16_ISSUE(it_kt, gi & 1)
+            ++gi;
+            if (++it_kt == KT) {
+                it_kt = 0;
+                if (++it_tile < my_ntiles) set_src(it_tile);
+            }
+        }
+        const char* Ab = smem + (g & 1) * STAGE;
+        const char* Bb = Ab + A_BYTES;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // two 32-wide k steps per 64-wide stage
+            v4f a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + swz_byte(wr * 128 + 16 * m + lq, 4 * c + lg));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + swz_byte(wc * 64 + 16 * n + lq, 4 * c + lg));
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, b[n]),
+                                                                        __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
+        }
+        if (++kt == KT) {
+            const int tile = xfirst + jx + ct_tile * per_x;
+            const int row0 = (tile / ntn) * BM + wr * 128 + lq, col0 = (tile % ntn) * BN + wc * 64;
+            float4 bv[TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bv[n] = *reinterpret_cast<const float4*>(&sbias[wc * 64 + 16 * n + 4 * lg]);
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const size_t rbase = (size_t)(row0 + 16 * m) * N + col0;  // may be a slack row
+                uint2 packed[TN];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    float4 v;
+                    v.x = acc[m][n][0] + bv[n].x;
+                    v.y = acc[m][n][1] + bv[n].y;
+                    v.z = acc[m][n][2] + bv[n].z;
+                    v.w = acc[m][n][3] + bv[n].w;
+                    if constexpr (EPI == EPI_GELU) {
+                        v.x = gelu_erf_fast(v.x); v.y = gelu_erf_fast(v.y); v.z = gelu_erf_fast(v.z); v.w = gelu_erf_fast(v.w);
+                    }
+                    if constexpr (EPI == EPI_QKV) {
+                        const float sc = col0 + 16 * n < qscale_cols ? qscale : 1.0f;  // qscale_cols is a multiple of 16
+                        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    }
+                    if constexpr (OUT32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cout) + rbase + 16 * n + 4 * lg) = v;
+                    } else if constexpr (OUT16) {
+                        packed[n].x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                        packed[n].y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                    } else {
+                        ushort4 h;
+                        h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+                        *reinterpret_cast<ushort4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + 16 * n + 4 * lg) = h;
+                    }
+                }
+                if constexpr (OUT16) {
+                    // lanes lg and lg ^ 1 hold adjacent 4-column groups of every 16-column tile: the even one takes
+                    // both halves of tile 2j, the odd one both halves of tile 2j+1 -> one 16-B store each
+#pragma unroll
+                    for (int j = 0; j < TN / 2; ++j) {
+                        const uint2 p0 = packed[2 * j], p1 = packed[2 * j + 1];
+                        const uint2 send = (lg & 1) ? p0 : p1;
+                        uint2 recv;
+                        recv.x = (unsigned)__shfl_xor((int)send.x, 16);
+                        recv.y = (unsigned)__shfl_xor((int)send.y, 16);
+                        const uint4 o = (lg & 1) ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+                        const int col = 16 * (2 * j + (lg & 1)) + 4 * (lg & ~1);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + col) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            ++ct_tile;
+        }
+    }
+#undef G16_ISSUE
+}
+
 // ---------------------------------------------------------------- skinny GEMM (M <= 64 tokens)
 // The single-query path (generate_single_embedding, src/embeddings.py:179-190) is a
 // weight-streaming problem: 85 MB of bf16 weights per forward, a few dozen tokens.  The big

@@ -396,19 +396,19 @@ def main():
         avg_s = ms / n / 1e3
         sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one fp32 sweep of this rank's shard
         if dom == "knn_scan_coarse_main":
-            # last stage of the cascade (k_scan_coarse<false,true>): the row tiles t with t % 4 != 0, i.e.
+            # last stage of the cascade (k_scan_coarse<false,true,..>): the row tiles t with t % 4 != 0, i.e.
             # 3/4 of the shard, one bf16 MFMA product per (row, query, 16 k); see css_knn_coarse.h
             ntiles = -(-shard // 256)
             main_tiles = (ntiles - 1) - (ntiles - 1) // 4
             main_rows = min(main_tiles * 256, shard)
             flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
             sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
-            roofline = {"bound": "mfma", "kernel": "k_scan_coarse<false,true> (main stage of the cascade)",
+            roofline = {"bound": "mfma", "kernel": "k_scan_coarse<false,true,false,16> (main stage of the cascade)",
                         "achieved": flops / avg_s / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None,
                         "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows,
                         "hbm_GBps": sweep_bytes / avg_s / 1e9,
-                        "arithmetic": "bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_32x32x16_bf16; "
+                        "arithmetic": "bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_16x16x32_bf16; "
                                       "candidates rescored in fp32",
                         "executed_mfma_TFLOPs": flops * (-(-args.nq // 256) * 256 / args.nq) / avg_s / 1e12}
             if "knn_coarse_cascade" in kernels:
@@ -435,7 +435,7 @@ def main():
     if roofline:
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
         wl = {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k}
-        tr = pmc_traffic({"knn_scan_mfma": "k_scan_mfma", "knn_scan_coarse_main": "k_scan_coarse<false, true>"}.get(dom, "k_scan_small"), wl)
+        tr = pmc_traffic({"knn_scan_mfma": "k_scan_mfma", "knn_scan_coarse_main": "k_scan_coarse<false, true"}.get(dom, "k_scan_small"), wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]

@@ -1315,7 +1315,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         const char* m = getenv("CSS_KNN_MFMA");
         mfma_shape = (m && atoi(m) == 32) ? 32 : 16;
     }
-    const scan_fn f_stage0 = k_scan_coarse<true, false>;
+    const scan_fn f_stage0 = mfma_shape == 16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>;
     const scan_fn f_mid = g_knn_dbg ? k_scan_coarse<false, false, true>
                                     : (mfma_shape == 16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
     const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true>

@@ -33,6 +33,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+CASCADE_GROWTH = 8 if os.environ.get("CSS_KNN_GROWTH") == "8" else 4   # growth factor of the coarse cascade (css_index.hip)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3    # dense fp32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak
@@ -396,10 +397,10 @@ def main():
         avg_s = ms / n / 1e3
         sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one fp32 sweep of this rank's shard
         if dom == "knn_scan_coarse_main":
-            # last stage of the cascade (k_scan_coarse<false,true,..>): the row tiles t with t % 4 != 0, i.e.
-            # 3/4 of the shard, one bf16 MFMA product per (row, query, 16 k); see css_knn_coarse.h
+            # last stage of the cascade (k_scan_coarse<false,true,..>): the row tiles t with t % g != 0 (g = 4), i.e.
+            # 3/4 of the shard, one bf16 MFMA product per (row, query, k); see css_knn_coarse.h
             ntiles = -(-shard // 256)
-            main_tiles = (ntiles - 1) - (ntiles - 1) // 4
+            main_tiles = (ntiles - 1) - (ntiles - 1) // CASCADE_GROWTH
             main_rows = min(main_tiles * 256, shard)
             flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
             sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
@@ -463,7 +464,7 @@ def main():
             ms, n = nat.prof_read("knn_sweep_coarse_main")
             if n:   # coarse sweep over the bf16 shadow rows: main stage = the row tiles t with t % 4 != 0
                 ntiles = -(-shard // 256)
-                main_rows = min(((ntiles - 1) - (ntiles - 1) // 4) * 256, shard)
+                main_rows = min(((ntiles - 1) - (ntiles - 1) // CASCADE_GROWTH) * 256, shard)
                 kbytes = main_rows * args.dim * 2
                 kname = "k_sweep_coarse<1, 6, true>"
             else:   # fp32 sweep (no shadow rows)

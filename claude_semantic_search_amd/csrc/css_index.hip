@@ -1239,26 +1239,26 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
 // Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [0, nq) of ix->qpad; nq <= 4096.
 // Returns the number of flagged queries (their ids in `flagged`) whose result must be recomputed on the exact path.
 template <int NQ, int TT, bool MAIN>
-int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, bool stage0,
+int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
                           hipStream_t st) {
     const size_t lds = (size_t)NQ * ix->dpad * sizeof(float);
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
     auto kern = k_sweep_coarse<NQ, TT, MAIN>;
     if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
-                       ix->ntotal, ix->dpad, nq, count, stride, stage0 ? 1 : 0, ix->cur_mask);
+                       ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, ix->cur_mask);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
 
 template <int NQ>
-int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, bool stage0,
+int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
                            hipStream_t st) {
     const bool main_stage = stride == 1 && !stage0;
     if (ix->dpad == 768)
-        return main_stage ? launch_sweep_coarse_t<NQ, 6, true>(ix, qpad, nq, count, stride, stage0, st)
-                          : launch_sweep_coarse_t<NQ, 6, false>(ix, qpad, nq, count, stride, stage0, st);
-    return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, stage0, st);
+        return main_stage ? launch_sweep_coarse_t<NQ, 6, true>(ix, qpad, nq, count, stride, gm1, stage0, st)
+                          : launch_sweep_coarse_t<NQ, 6, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
+    return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
 }
 
 // sweep = true: 1..4 queries through the HBM-bound bf16 sweep (k_sweep_coarse) instead of the MFMA scan.
@@ -1286,7 +1286,17 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // cascade schedule: stage 0 reads every s0-th row tile (2..7 tiles), then strides s0/4 ... 1
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
     int64_t s0 = 1;
-    while (ntiles / (s0 * 4) >= 2) s0 *= 4;
+    // growth factor g of the nested sample: every stage reads g-1 times the tiles read before it.  g = 4: the last
+    // stage is 3/4 of the rows and appends ~3k + band candidates per query.  g = 8 (CSS_KNN_GROWTH=8; stage 0 then
+    // holds up to 15 tiles = 3840 rows per query, still inside the 4096-slot buffer) measured 2 % slower for batches
+    // (more appends in the main stage) and the same for single queries.
+    static int growth = -1;
+    if (growth < 0) {
+        const char* m = getenv("CSS_KNN_GROWTH");
+        growth = (m && atoi(m) == 8) ? 8 : 4;
+    }
+    const int g = growth;
+    while (ntiles / (s0 * g) >= 2) s0 *= g;
     const int64_t n0 = (ntiles + s0 - 1) / s0;
 
     {
@@ -1302,7 +1312,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int*, const uint32_t*, int);
+                            int, int64_t, int64_t, int, int*, const uint32_t*, int);
     if (g_knn_dbg < 0) {
         const char* m = getenv("CSS_KNN_DBG");
         g_knn_dbg = m ? atoi(m) : 0;
@@ -1339,22 +1349,22 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     int stage_idx = 0;
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
-    for (int64_t s = s0;; s /= 4) {
+    for (int64_t s = s0;; s /= g) {
         const bool stage0 = s == s0;
         const int64_t W = (ntiles + s - 1) / s;
-        const int64_t count = stage0 ? W : (W - 1) - (W - 1) / 4;
+        const int64_t count = stage0 ? W : (W - 1) - (W - 1) / g;
         if (count > 0 && sweep) {
             ProfScope ps(s == 1 && !stage0 ? "knn_sweep_coarse_main" : "knn_sweep_coarse_stage", st);
-            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, stage0, st);
-            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, stage0, st);
-            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, stage0, st);
+            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, g - 1, stage0, st);
+            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, g - 1, stage0, st);
+            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, g - 1, stage0, st);
             if (rc != CSS_OK) return rc;
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, pace, ix->cur_mask, g_knn_dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, g_knn_dbg);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
-                                                     int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
+                                                     int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
                                                      int dbg_arg) {
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     }
     auto tile_of = [&](int ti) -> int64_t {
         const int64_t u = u0 + (int64_t)ti * ustep;
-        return (STAGE0 ? u : u + u / 3 + 1) * stride;
+        return (STAGE0 ? u : u + u / gm1 + 1) * stride;  // the multiples of the growth factor belong to earlier stages
     };
     auto set_src = [&](int ti) {
         const int64_t r0 = tile_of(ti) * CZ_T;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                                                       const float* __restrict__ qpad, const float* __restrict__ thr,
                                                       float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                       int* __restrict__ cand_n, int64_t ntotal, int dpad, int nq,
-                                                      int64_t count, int64_t stride, int stage0,
+                                                      int64_t count, int64_t stride, int gm1, int stage0,
                                                       const uint32_t* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][dpad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
     __syncthreads();
     const int steps = TT > 0 ? TT : (dpad + 127) / 128;
     for (int64_t u = blockIdx.x; u < count; u += gridDim.x) {
-        const int64_t tile = (stage0 ? u : u + u / 3 + 1) * stride;
+        const int64_t tile = (stage0 ? u : u + u / gm1 + 1) * stride;
         const int64_t row_base = tile * CZ_T + wave * 64;
 #pragma unroll 1
         for (int it = 0; it < 16; it += 2) {

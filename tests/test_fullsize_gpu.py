@@ -74,3 +74,29 @@ def test_10m_query_batch_mfma_path_and_agreement(big_index):
         big_index.set_search_mode("auto")
     assert np.abs(De - Db[:40]).max() < 1e-5 and (Ie == Ib[:40]).mean() > 0.97
     assert np.abs(D1 - Db[:2]).max() < 1e-5 and (I1 == Ib[:2]).mean() > 0.9
+
+
+def test_1m_clustered_rows_auto_mode_equals_exact_mode():
+    """Dense candidate bands at scale: 1 M rows in 2 000 tight clusters (cosine spread ~1e-3 inside a cluster), queries
+    near cluster centres and random ones, 1 and 300 queries.  The product path (bf16 candidate scan + fp32
+    rescoring, flagged queries re-run exactly) must return what the exact fp32 kernels return."""
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, nc = 1_000_000, 2000
+    cent = synth.rows(nc, D, 71)
+    ix = IndexFlatIP(D)
+    ix.reserve(n)
+    for c0 in range(0, n, 100_000):
+        ids = (np.arange(c0, c0 + 100_000) % nc)
+        ix.add(cent[ids] + 0.05 * synth.rows(100_000, D, 72 + c0 // 100_000), normalize=True)
+    q = np.concatenate([cent[:200] + 0.02 * synth.rows(200, D, 90), synth.rows(100, D, 91)])
+    for nq in (1, 300):
+        ix.set_search_mode("auto")
+        Da, Ia = ix.search(q[:nq], K, normalize=True)
+        ix.set_search_mode("exact_fp32")
+        De, Ie = ix.search(q[:nq], K, normalize=True)
+        assert np.abs(Da - De).max() < 1e-5
+        assert (Ia == Ie).mean() > 0.995          # fp32 near-ties inside a cluster may swap between summation orders
+        assert (np.sort(Ia, axis=1) == np.sort(Ie, axis=1)).mean() > 0.995
+    ix.close()

@@ -1436,7 +1436,12 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         g_knn_batch_coarse = (m && (std::string(m) == "fp32" || std::string(m) == "split")) ? 0 : 1;
     }
     // coarse paths need room for k rows in stage 0 (always true) and the bf16 shadow rows
-    if (g_knn_batch_coarse && ix->search_mode == CSS_SEARCH_AUTO && ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
+    // The cascade costs ~10-16 launches and one host round trip: below these sizes (measured on MI355X, 768-d:
+    // 1 query 0.18 vs 0.13 ms at 10 k rows, crossover ~1.2 M; 8 queries crossover ~0.4 M; 32+ queries always
+    // ahead) the exact fp32 kernels answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
+    const bool coarse_pays = nq > 16 || (nq > 4 ? ix->ntotal >= 400000 : ix->ntotal >= 1200000);
+    if (g_knn_batch_coarse && (ix->search_mode == CSS_SEARCH_COARSE || (coarse_pays && ix->search_mode == CSS_SEARCH_AUTO)) &&
+        ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
         std::vector<int> flagged;
         if (nq <= 4) {  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
             if ((rc = launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, &flagged, true)) != CSS_OK) return rc;
@@ -1560,7 +1565,8 @@ int css_index_device(const css_index* ix, int* device) {
 
 int css_index_set_search_mode(css_index* ix, int mode) {
     CSS_REQUIRE(ix, "css_index_set_search_mode: NULL index");
-    CSS_REQUIRE(mode == CSS_SEARCH_AUTO || mode == CSS_SEARCH_EXACT_FP32, "css_index_set_search_mode: unknown mode %d", mode);
+    CSS_REQUIRE(mode == CSS_SEARCH_AUTO || mode == CSS_SEARCH_EXACT_FP32 || mode == CSS_SEARCH_COARSE,
+                "css_index_set_search_mode: unknown mode %d", mode);
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     ix->search_mode = mode;
     return CSS_OK;

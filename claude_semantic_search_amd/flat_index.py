@@ -135,9 +135,10 @@ class IndexFlat:
                                                         ctypes.c_void_p(stream)))
 
     def set_search_mode(self, mode: str) -> None:
-        """``"auto"`` (default: bf16 candidate scan + exact fp32 rescoring when the index keeps
-        shadow rows) or ``"exact_fp32"`` (every score formed in fp32 by the scan kernels)."""
-        modes = {"auto": 0, "exact_fp32": 1}
+        """``"auto"`` (default: bf16 candidate scan + exact fp32 rescoring where the index keeps shadow
+        rows and is large enough for it to pay), ``"exact_fp32"`` (every score formed in fp32 by the
+        scan kernels) or ``"coarse"`` (the candidate path whatever the index size)."""
+        modes = {"auto": 0, "exact_fp32": 1, "coarse": 2}
         if mode not in modes:
             raise ValueError(f"unknown search mode {mode!r}")
         nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))

@@ -110,6 +110,7 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * also what L2 indexes and indexes without shadow rows always use). */
 #define CSS_SEARCH_AUTO 0
 #define CSS_SEARCH_EXACT_FP32 1
+#define CSS_SEARCH_COARSE 2 /* the candidate path whatever the index size (AUTO uses it only where it pays) */
 int css_index_set_search_mode(css_index* ix, int mode);
 int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
                      float* D_host, int64_t* I_host);

@@ -92,7 +92,7 @@ def test_1m_clustered_rows_auto_mode_equals_exact_mode():
         ix.add(cent[ids] + 0.05 * synth.rows(100_000, D, 72 + c0 // 100_000), normalize=True)
     q = np.concatenate([cent[:200] + 0.02 * synth.rows(200, D, 90), synth.rows(100, D, 91)])
     for nq in (1, 300):
-        ix.set_search_mode("auto")
+        ix.set_search_mode("coarse")
         Da, Ia = ix.search(q[:nq], K, normalize=True)
         ix.set_search_mode("exact_fp32")
         De, Ie = ix.search(q[:nq], K, normalize=True)

@@ -29,7 +29,7 @@ def _run_case(n, d, nq, k, metric, normalize, seed=1):
     D64 = ref.rescore64(qr, np.where(Ir < 0, 0, Ir))
     # both search paths against the oracle: "exact_fp32" (every score formed in fp32 by the scan kernels: the
     # parity mode) and "auto" (the product default: bf16 candidate scan + exact fp32 rescoring where available)
-    for mode in ("exact_fp32", "auto"):
+    for mode in ("exact_fp32", "coarse", "auto"):
         hip.set_search_mode(mode)
         D, I = hip.search(q, k, normalize=normalize)
         assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}")
@@ -125,7 +125,7 @@ def test_committed_goldens_on_hip():
         ix = IndexFlat(int(g["d"]), metric)
         ix.add_synthetic(int(g["n"]), int(g["seed_x"]), 0, normalize=norm)
         q = synth.rows(int(g["nq"]), int(g["d"]), int(g["seed_q"]))
-        for mode in ("exact_fp32", "auto"):
+        for mode in ("exact_fp32", "coarse", "auto"):
             ix.set_search_mode(mode)
             D, I = ix.search(q, int(g["k"]), normalize=norm)
             assert_topk_matches(D, I, g["D"], g["I"].astype(np.int64), g["D64"], f"{name} [{mode}]")
@@ -240,6 +240,7 @@ def _check_against_oracle(x, q, k, normalize, what):
 
     ix = IndexFlatIP(x.shape[1])
     ix.add(x, normalize=normalize)
+    ix.set_search_mode("coarse")          # (auto would pick the exact kernels for an index this small)
     D, I = ix.search(q, k, normalize=normalize)
     ref = ko.FlatIndexOracle(x.shape[1], 0)
     xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if normalize else (x, q)
@@ -280,6 +281,7 @@ def test_coarse_raw_inner_product_wide_norms():
 
     ix = IndexFlatIP(768)
     ix.add(x, normalize=False)
+    ix.set_search_mode("coarse")
     D, I = ix.search(q, 10, normalize=False)
     ref = ko.FlatIndexOracle(768, 0)
     ref.add(x)
@@ -301,6 +303,7 @@ def test_coarse_and_split_paths_agree(monkeypatch):
     q = synth.rows(64, 768, 52)
     ix = IndexFlatIP(768)
     ix.add(x, normalize=True)
+    ix.set_search_mode("coarse")
     D, I = ix.search(q, 10, normalize=True)
     for r in range(0, 64, 9):
         d1, i1 = ix.search(q[r:r + 1], 10, normalize=True)
@@ -329,7 +332,7 @@ def test_masked_search_matches_oracle_on_the_allowed_rows(metric, nq, density):
     Dr, Ir = ref.search(qr, k)
     D64 = ref.rescore64(qr, Ir)
     Ir = sub[Ir]
-    for mode in ("exact_fp32", "auto"):
+    for mode in ("exact_fp32", "coarse", "auto"):
         ix.set_search_mode(mode)
         D, I = ix.search(q, k, normalize=norm, allow=allow)
         assert allow[I].all()
@@ -345,6 +348,7 @@ def test_masked_search_with_few_or_no_allowed_rows_pads():
     ix.add(x, normalize=True)
     allow = np.zeros(5000, dtype=bool)
     allow[[7, 4000, 4999]] = True
+    ix.set_search_mode("coarse")
     for nq in (1, 20):
         D, I = ix.search(x[:nq], 5, normalize=True, allow=allow)
         assert (np.sort(I[:, :3], axis=1) == np.array([7, 4000, 4999])).all() and (I[:, 3:] == -1).all()

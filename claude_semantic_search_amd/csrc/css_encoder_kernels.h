@@ -166,18 +166,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const TPre* __restrict__ in, 
 // ---------------------------------------------------------------- GEMM
 // C[M,N] = A[M,K] * W[N,K]^T (+ epilogue).  Both operands are K-contiguous, so A
 // and W fragments are 16-B rows-of-K vectors.  Block = WM x WN waves, each wave a
-// (32*TM) x (32*TN) output tile; K-step = 64 bytes of K (32 bf16 / 16 f32).
+// (32*TM) x (32*TN) output tile; a ring stage holds RB bytes of K per row.
 //
-// Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction = 16 rows
-// x 64 B, lane i -> row i/4, physical 16-B chunk i%4) into a 4-deep ring of stages
-// with COUNTED vmcnt and a raw s_barrier: while stage s is multiplied, stages s+1,
-// s+2, s+3 are in flight (up to 96 KiB per CU for a 256x256 tile).  Measured on
-// MI355X (tools/probe_l2bw.hip): a CU's L2->LDS rate is latency x concurrency bound
-// (~1.3 us under load): 16/32/64 KiB in flight give 29/37/48 GB/s per CU, so the
-// 2-stage version of this kernel (one 64-KiB stage in flight) was load bound.
-// LDS rows are 64 B; physical chunk = logical ^ ((row>>2)&3) makes every
-// ds_read_b128 lane group hit 16 distinct 16-B slots; the swizzle is applied on the
-// per-lane SOURCE address of the DMA (its LDS destination is linear) and on reads.
+// Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction) into a ring of NST
+// stages with COUNTED vmcnt and a raw s_barrier.  The product configuration is 2 stages x 64 KiB
+// (256 + 256 rows x 128 B): measured on MI355X, a CU takes ~45-49 GB/s into LDS whatever the
+// number of stages in flight (a bandwidth limit), and rings of 3-5 smaller stages only added
+// barriers.  The 128x128 configuration (small shapes) keeps a 4 x 16 KiB ring of 64-B rows.
+// LDS rows of 128 B: physical 16-B chunk = logical ^ ((row>>1)&7); rows of 64 B: logical ^
+// ((row>>2)&3): every ds_read_b128 lane group hits 16 distinct slots.  The swizzle is applied
+// on the per-lane SOURCE address of the DMA (its LDS destination is linear) and on reads.
+// k_gemm16 (below) is the product-mode twin of the 256x256 bf16 configuration on 16x16x32 MFMAs.
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
 template <typename TIn>

@@ -251,10 +251,12 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
     auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB, SPS>;
     const size_t lds = (size_t)NST * (BM + BN) * RB;  // ring of NST stages, RB bytes of K per row
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per instantiation and device (the attribute belongs to the device's code object)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
         CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_ & 63] = true;
     }
     const int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     int grid = std::min(ntn * ntm, num_cus * blocks_per_cu);
@@ -294,10 +296,12 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M,
                 CSS_REQUIRE(K % 64 == 0 && K / 64 >= 3, "gemm: K=%d must be a multiple of 64 (>= 192)", K);
                 auto kern = k_gemm16<EPI>;
                 constexpr size_t lds = 2 * 512 * 128;
-                static bool attr_set = false;  // per instantiation
-                if (!attr_set) {
+                static bool attr_set[64] = {};  // per instantiation and device
+                int dev_ = 0;
+                (void)hipGetDevice(&dev_);
+                if (!attr_set[dev_ & 63]) {
                     CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_set = true;
+                    attr_set[dev_ & 63] = true;
                 }
                 const int ntiles = (N / 256) * ((M + 255) / 256);
                 int grid = std::min(ntiles, num_cus);

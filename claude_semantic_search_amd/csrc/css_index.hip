@@ -1330,11 +1330,11 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
                                     : (mfma_shape == 16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
     const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true>
                                      : (mfma_shape == 16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's code object
+    if (!attr_set[ix->device & 63]) {
         for (scan_fn f : {f_stage0, f_mid, f_main})
             CSS_HIP_TRY(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[ix->device & 63] = true;
     }
     const int grid = std::max(8, ix->num_cus / 8 * 8);
     static int pacing = -1;  // CSS_KNN_PACE=0 disables the sibling pacing of k_scan_coarse (A/B experiments)

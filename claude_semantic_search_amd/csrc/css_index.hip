@@ -1003,7 +1003,7 @@ __global__ void k_fill_int(int* p, int n, int v) {
 // of 64-element K stages and fp32 + bf16 rows fit in 80 % of the HBM (CSS_KNN_SHADOW=0/1 overrides).
 bool want_shadow(css_index* ix, int64_t ncap) {
     if (ix->shadow == 0) return false;
-    if (ix->metric != CSS_METRIC_IP || ix->dpad % 64 != 0) return false;
+    if (ix->dpad % 64 != 0) return false;
     const char* e = getenv("CSS_KNN_SHADOW");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
@@ -1019,7 +1019,7 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
     unsigned short* nxh = nullptr;
     hipError_t e = hipMalloc((void**)&nxb, (size_t)ncap * ix->dpad * sizeof(float));
     if (e != hipSuccess) return css::hip_fail(e, "hipMalloc(index rows)", __FILE__, __LINE__);
-    e = hipMalloc((void**)&nn2, (size_t)ncap * sizeof(float));
+    e = hipMalloc((void**)&nn2, ((size_t)ncap + 256) * sizeof(float));  // +256: the coarse scan reads whole tiles of norms
     if (e != hipSuccess) {
         (void)hipFree(nxb);
         return css::hip_fail(e, "hipMalloc(index norms)", __FILE__, __LINE__);
@@ -1246,7 +1246,8 @@ int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t coun
     auto kern = k_sweep_coarse<NQ, TT, MAIN>;
     if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
-                       ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, ix->cur_mask);
+                       ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, ix->cur_mask,
+                       ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1272,6 +1273,8 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     const float eps_rel = sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f;
+    const int l2 = ix->metric == CSS_METRIC_L2 ? 1 : 0;
+    const float* xn2 = l2 ? ix->xnorm2 : nullptr;  // L2: coarse score = 2 x.q - ||x||^2
     int rc;
     if (!sweep && (rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cthr, &ix->cthr_cap, (size_t)nq_pad)) != CSS_OK) return rc;
@@ -1312,7 +1315,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int, int*, const uint32_t*, int);
+                            int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int);
     if (g_knn_dbg < 0) {
         const char* m = getenv("CSS_KNN_DBG");
         g_knn_dbg = m ? atoi(m) : 0;
@@ -1364,19 +1367,19 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, g_knn_dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, xn2, g_knn_dbg);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;
         if (s == 1) {
             hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, k, qpad, ix->xb, ix->dpad,
+                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
                                ix->id_base, D_dev, I_dev);
             CSS_LAUNCH_CHECK();
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, k, qpad, ix->xb, ix->dpad,
+                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
                            ix->id_base, D_dev, I_dev);
         CSS_LAUNCH_CHECK();
     }
@@ -1441,7 +1444,7 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     // ahead) the exact fp32 kernels answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
     const bool coarse_pays = nq > 16 || (nq > 4 ? ix->ntotal >= 400000 : ix->ntotal >= 1200000);
     if (g_knn_batch_coarse && (ix->search_mode == CSS_SEARCH_COARSE || (coarse_pays && ix->search_mode == CSS_SEARCH_AUTO)) &&
-        ix->metric == CSS_METRIC_IP && ix->xh != nullptr) {
+        ix->xh != nullptr) {
         std::vector<int> flagged;
         if (nq <= 4) {  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
             if ((rc = launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, &flagged, true)) != CSS_OK) return rc;
@@ -1453,7 +1456,9 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         }
         if (flagged.empty()) return CSS_OK;
         // candidate buffer / band overflow (e.g. thousands of duplicate rows): exact path for those queries
-        if (flagged.size() > 32 && nq > 16 && k <= kMfmaMaxK) return launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st);
+        if (flagged.size() > 32 && nq > 16 && k <= kMfmaMaxK)
+            return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
+                                               : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
         if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
         for (int q : flagged)
             if ((rc = search_chunk_small(ix, q, 1, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;

@@ -70,6 +70,19 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
 #define CZ_EPILOGUE()                                                                                        \
             const int64_t tile = tile_of(ct_tile);                                                                     \
             const int64_t row0 = tile * CZ_T + wc * 64;                                                                \
+            if (xn2 != nullptr) { /* L2: score = 2 x.q - ||x||^2 (||q||^2 is the same for every row of a query) */ \
+_Pragma("unroll")                                                                                                      \
+                for (int n = 0; n < TN; ++n)                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int rg = 0; rg < NR / 4; ++rg) {                                                              \
+                        const float4 xv = *reinterpret_cast<const float4*>(xn2 + row0 + CZ_ROFF(n, 4 * rg));           \
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};                                                  \
+_Pragma("unroll")                                                                                                      \
+                        for (int m = 0; m < TM; ++m)                                                                   \
+_Pragma("unroll")                                                                                                      \
+                            for (int e = 0; e < 4; ++e) acc[m][n][4 * rg + e] = fmaf(2.f, acc[m][n][4 * rg + e], -xs[e]); \
+                    }                                                                                                  \
+            }                                                                                                          \
             if (dbg & 1) {                                                                                             \
             } else if constexpr (STAGE0) {                                                                             \
                 const int64_t u = u0 + (int64_t)ct_tile * ustep;                                                       \
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
                                                      int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
-                                                     int dbg_arg) {
+                                                     const float* __restrict__ xn2, int dbg_arg) {
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
     // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                                                       float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                       int* __restrict__ cand_n, int64_t ntotal, int dpad, int nq,
                                                       int64_t count, int64_t stride, int gm1, int stage0,
-                                                      const uint32_t* __restrict__ mask) {
+                                                      const uint32_t* __restrict__ mask, const float* __restrict__ xn2) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][dpad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
     for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq ? qpad[i] : 0.f;
@@ -403,13 +416,18 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                     }
                 }
             }
+            float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
+            if (xn2 != nullptr) {
+                xa = xn2[rowA < ntotal ? rowA : ntotal - 1];
+                xb2 = xn2[rowB < ntotal ? rowB : ntotal - 1];
+            }
             float ma = 0.f, mb = 0.f;  // score of query `sub` for this lane's row
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
                 if (sub == j) {
-                    ma = ra;
-                    mb = rb;
+                    ma = xn2 != nullptr ? fmaf(2.f, ra, -xa) : ra;
+                    mb = xn2 != nullptr ? fmaf(2.f, rb, -xb2) : rb;
                 }
             }
             if (sub < nq) {
@@ -470,7 +488,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                                                        int* __restrict__ cand_n, float* __restrict__ thr,
                                                        int* __restrict__ flags, int* __restrict__ nflag,
                                                        int* __restrict__ flag_list, const float* __restrict__ qnorm2,
-                                                       const int* __restrict__ maxn2_bits, float eps_rel, int k,
+                                                       const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
                                                        const float* __restrict__ qpad, const float* __restrict__ xb,
                                                        int dpad, int64_t id_base, float* __restrict__ D,
                                                        int64_t* __restrict__ I) {
@@ -490,7 +508,11 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     if (tid == 0) cnt = 0;
     cz_bitonic(s, id, P, tid);
     const float Tc = n >= k ? s[k - 1] : -INFINITY;
-    const float eps = eps_rel * sqrtf(qnorm2[q]) * sqrtf(__int_as_float(*maxn2_bits)) + 1e-30f;
+    // IP: |c - x.q| <= eps_rel ||q|| max||x||.  L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2):
+    // twice that, plus the fp32 cancellation of the expanded form
+    const float mx2 = __int_as_float(*maxn2_bits);
+    float eps = eps_rel * sqrtf(qnorm2[q]) * sqrtf(mx2) + 1e-30f;
+    if (l2) eps = 2.f * eps + 9.5367431640625e-07f * (mx2 + qnorm2[q]);
     const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
     int c = 0;
     for (int i = tid; i < n; i += 256) c += (s[i] >= thr_new && id[i] != kInvalidRow) ? 1 : 0;
@@ -517,15 +539,26 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
         for (int cidx = wave; cidx < R; cidx += 4) {
             const float4* xv = reinterpret_cast<const float4*>(xb + (size_t)id[cidx] * dpad);
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int j = lane; j < (dpad >> 2); j += 64) {
-                const float4 x = xv[j], y = qv[j];
-                a0 = fmaf(x.x, y.x, a0);
-                a1 = fmaf(x.y, y.y, a1);
-                a2 = fmaf(x.z, y.z, a2);
-                a3 = fmaf(x.w, y.w, a3);
+            if (l2) {  // -(squared distance), formed directly as the exact kernels do
+                for (int j = lane; j < (dpad >> 2); j += 64) {
+                    const float4 x = xv[j], y = qv[j];
+                    const float dx = x.x - y.x, dy = x.y - y.y, dz = x.z - y.z, dw = x.w - y.w;
+                    a0 = fmaf(dx, dx, a0);
+                    a1 = fmaf(dy, dy, a1);
+                    a2 = fmaf(dz, dz, a2);
+                    a3 = fmaf(dw, dw, a3);
+                }
+            } else {
+                for (int j = lane; j < (dpad >> 2); j += 64) {
+                    const float4 x = xv[j], y = qv[j];
+                    a0 = fmaf(x.x, y.x, a0);
+                    a1 = fmaf(x.y, y.y, a1);
+                    a2 = fmaf(x.z, y.z, a2);
+                    a3 = fmaf(x.w, y.w, a3);
+                }
             }
             const float e = wave_allsum((a0 + a1) + (a2 + a3));
-            if (lane == 0) s[cidx] = e;
+            if (lane == 0) s[cidx] = l2 ? -e : e;
         }
         int P2 = 2;
         while (P2 < R) P2 <<= 1;
@@ -537,7 +570,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
         cz_bitonic(s, id, P2, tid);
         for (int i = tid; i < k; i += 256) {
             const bool ok = i < R && id[i] != kInvalidRow;
-            D[(size_t)q * k + i] = ok ? s[i] : -FLT_MAX;
+            D[(size_t)q * k + i] = l2 ? (ok ? -s[i] : FLT_MAX) : (ok ? s[i] : -FLT_MAX);
             I[(size_t)q * k + i] = ok ? id_base + (int64_t)id[i] : (int64_t)-1;
         }
     }

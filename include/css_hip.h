@@ -99,8 +99,8 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * distances.  Ties: lower id first.  Fewer than k rows: I = -1 and
  * D = -FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= CSS_MAX_K.
  * normalize_q != 0 applies q / (||q||_2 + 1e-8) first (src/storage.py:426).
- * Inner-product indexes keep a bf16 shadow copy of the rows while it fits in
- * HBM; searches then select candidates with a bf16 scan inside a rigorous
+ * Indexes keep a bf16 shadow copy of the rows while it fits in HBM; searches
+ * of large indexes then select candidates with a bf16 scan inside a rigorous
  * error band and return exact fp32 scores of the rescored candidates (same
  * results as the fp32 kernels).  The _dev form enqueues on `stream`; on that
  * candidate path it also waits for the stream once per call (overflow check). */

@@ -290,6 +290,60 @@ def test_coarse_raw_inner_product_wide_norms():
     ix.close()
 
 
+@pytest.mark.parametrize("nq", [1, 3, 40, 300])
+def test_coarse_l2_raw_rows_and_duplicates(nq):
+    # squared-L2 through the candidate path: un-normalised rows with norms over a decade, 40 exact duplicates of
+    # one row (ties -> lowest ids first), queries that ARE rows (distance 0)
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatL2
+
+    rng = np.random.default_rng(8)
+    x = synth.rows(20000, 768, 81) * (10.0 ** rng.uniform(-0.5, 0.5, (20000, 1))).astype(np.float32)
+    x[5000:5040] = x[123]
+    q = np.concatenate([x[[123, 7, 19999]], synth.rows(max(nq - 3, 0), 768, 82)])[:nq]
+    ix = IndexFlatL2(768)
+    ix.add(x)
+    ref = ko.FlatIndexOracle(768, 1)
+    ref.add(x)
+    Dr, Ir = ref.search(q, 10)
+    D64 = ref.rescore64(q, Ir)
+    gaps = np.abs(np.diff(D64, axis=1))
+    safe = np.ones_like(Ir, dtype=bool)      # ids must agree wherever the fp64 gap exceeds 1e-5 of the norm scale (~8e3)
+    safe[:, 1:] &= gaps > 0.1
+    safe[:, :-1] &= gaps > 0.1
+    safe[:, -1] = False                      # (the gap to rank k+1 is not known here)
+    for mode in ("exact_fp32", "coarse"):
+        ix.set_search_mode(mode)
+        D, I = ix.search(q, 10)
+        # squared norms here reach ~8e3: the bar is relative to them (fp32 has 7 digits; the batched exact kernel
+        # uses faiss' expanded form ||q||^2 - 2 x.q + ||x||^2, whose self distance is ~1e-6 ||x||^2, not 0)
+        assert np.allclose(D, Dr, rtol=2e-6, atol=1e-2), f"[{mode}] {np.abs(D - Dr).max()}"
+        assert (I[safe] == Ir[safe]).all(), f"[{mode}] id mismatch"
+        assert I[0, 0] == 123 and D[0, 0] < 1e-2 and I[0, 1] == 5000
+    ix.close()
+
+
+def test_candidate_path_really_runs_for_both_metrics():
+    # in-library timing scopes show which kernels ran: on ordinary data the coarse cascade answers alone
+    # (no exact re-run), for inner product and for squared L2
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    for metric, norm in ((0, True), (1, False)):
+        ix = IndexFlat(768, metric)
+        ix.add(synth.rows(30000, 768, 91), normalize=norm)
+        ix.set_search_mode("coarse")
+        for nq, scope in ((64, "knn_coarse_cascade"), (2, "knn_sweep_cascade")):
+            nat.prof_reset()
+            nat.prof_enable(True)
+            ix.search(synth.rows(nq, 768, 92), 10, normalize=norm)
+            nat.prof_enable(False)
+            assert nat.prof_read(scope)[1] == 1
+            assert nat.prof_read("knn_scan_mfma")[1] == 0 and nat.prof_read("knn_scan_small")[1] == 0
+        nat.prof_reset()
+        ix.close()
+
+
 @pytest.mark.parametrize("n,nq,k", [(9000, 40, 100), (9000, 33, 128), (700, 4200, 10), (257, 513, 3)])
 def test_coarse_large_k_and_query_chunks(n, nq, k):
     _run_case(n, 768, nq, k, 0, True, seed=n + k)

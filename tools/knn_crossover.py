@@ -2,12 +2,13 @@
 import sys, time
 sys.path.insert(0, ".")
 import torch
-from claude_semantic_search_amd.flat_index import IndexFlatIP
+from claude_semantic_search_amd.flat_index import IndexFlatIP, IndexFlatL2
 from claude_semantic_search_amd import synth
 
 st = torch.cuda.current_stream().cuda_stream
-for rows in (10_000, 100_000, 500_000, 1_000_000, 2_000_000, 4_000_000):
-    ix = IndexFlatIP(768)
+metric = sys.argv[1] if len(sys.argv) > 1 else "ip"
+for rows in (10_000, 100_000, 500_000, 1_000_000, 2_000_000, 4_000_000, 10_000_000):
+    ix = IndexFlatIP(768) if metric == "ip" else IndexFlatL2(768)
     ix.reserve(rows)
     ix.add_synthetic(rows, seed=7)
     line = [f"N={rows:8d}"]

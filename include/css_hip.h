@@ -105,9 +105,10 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * results as the fp32 kernels).  The _dev form enqueues on `stream`; on that
  * candidate path it also waits for the stream once per call (overflow check). */
 /* Search path: CSS_SEARCH_AUTO (default) selects candidates with the bf16 scan and
- * rescores them in fp32 whenever the index keeps shadow rows; CSS_SEARCH_EXACT_FP32
- * forms every score in fp32 inside the scan kernels (the parity mode of the tests;
- * also what L2 indexes and indexes without shadow rows always use). */
+ * rescores them in fp32 when the index keeps shadow rows and is large enough for the
+ * multi-launch cascade to pay (one query: >= 1.2 M rows); CSS_SEARCH_EXACT_FP32 forms
+ * every score in fp32 inside the scan kernels (the parity mode of the tests; also what
+ * small indexes and indexes without shadow rows use). */
 #define CSS_SEARCH_AUTO 0
 #define CSS_SEARCH_EXACT_FP32 1
 #define CSS_SEARCH_COARSE 2 /* the candidate path whatever the index size (AUTO uses it only where it pays) */

@@ -474,12 +474,17 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
                                                 int K, int qscale_cols, float qscale) {
     constexpr int NW = 8, WN = 4, TM = 8, TN = 4, BM = 256, BN = 256, RB = 128;
     constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB, PPW = 8;
-    constexpr bool OUT16 = EPI == EPI_QKV;            // 16-B bf16 stores after a half exchange with lane ^ 16
-    constexpr bool OUT32 = EPI == EPI_RESID;          // fp32 rows
-    constexpr int E = OUT16 ? TM * TN / 2 : TM * TN;  // store instructions per wave per tile
+    constexpr bool OUT32 = EPI == EPI_RESID;          // fp32 rows (verification-style residual storage)
+    constexpr int E = OUT32 ? TM * TN : 2 * TM;       // store instructions per wave per tile (vmcnt bookkeeping)
     static_assert(E <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A_BYTES | B_BYTES]
     __shared__ __attribute__((aligned(16))) float sbias[BN];
+    // bf16 outputs leave through a per-wave LDS transpose (16 token rows x 64 columns at a time): a lane owns 4
+    // columns of one row, so direct stores scatter 8-B pieces over 64 rows per instruction (one L2 transaction
+    // each: ~4-8 us per tile); after the transpose 8 lanes write one full 128-B line.  Rows are padded to 144 B
+    // (16 rows fall on 16 different bank groups).
+    constexpr int EPI_ROW = 144;
+    __shared__ __attribute__((aligned(16))) char sepi[NW][16 * EPI_ROW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
 #pragma unroll
             for (int m = 0; m < TM; ++m) {
                 const size_t rbase = (size_t)(row0 + 16 * m) * N + col0;  // may be a slack row
-                uint2 packed[TN];
+                char* mine = sepi[wave];
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
                     float4 v;
@@ -603,28 +608,21 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
                     }
                     if constexpr (OUT32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cout) + rbase + 16 * n + 4 * lg) = v;
-                    } else if constexpr (OUT16) {
-                        packed[n].x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-                        packed[n].y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
                     } else {
-                        ushort4 h;
-                        h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
-                        *reinterpret_cast<ushort4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + 16 * n + 4 * lg) = h;
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                        *reinterpret_cast<uint2*>(mine + lq * EPI_ROW + (16 * n + 4 * lg) * 2) = pk;
                     }
                 }
-                if constexpr (OUT16) {
-                    // lanes lg and lg ^ 1 hold adjacent 4-column groups of every 16-column tile: the even one takes
-                    // both halves of tile 2j, the odd one both halves of tile 2j+1 -> one 16-B store each
+                if constexpr (!OUT32) {
+                    // read the 16 x 64 block back row-wise: lane j -> row 8 t + (j >> 3), 16-B chunk j & 7
 #pragma unroll
-                    for (int j = 0; j < TN / 2; ++j) {
-                        const uint2 p0 = packed[2 * j], p1 = packed[2 * j + 1];
-                        const uint2 send = (lg & 1) ? p0 : p1;
-                        uint2 recv;
-                        recv.x = (unsigned)__shfl_xor((int)send.x, 16);
-                        recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-                        const uint4 o = (lg & 1) ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
-                        const int col = 16 * (2 * j + (lg & 1)) + 4 * (lg & ~1);
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cout) + rbase + col) = o;
+                    for (int t = 0; t < 2; ++t) {
+                        const int rr = 8 * t + (lane >> 3);
+                        const uint4 o = *reinterpret_cast<const uint4*>(mine + rr * EPI_ROW + (lane & 7) * 16);
+                        const size_t g = (size_t)((tile / ntn) * BM + wr * 128 + 16 * m + rr) * N + col0 + (lane & 7) * 8;
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cout) + g) = o;
                     }
                 }
             }

@@ -88,3 +88,48 @@ def test_pipelined_encode_and_native_tokenizer_with_a_vocab_file(tmp_path):
     for i in (0, 1, 1023, 1024, 1500, 2499):
         assert np.allclose(out[i], enc.encode(texts[i]), atol=2e-3)
     enc.close()
+
+
+def test_config1_shape_encode_index_search_vs_the_reference_path():
+    """BASELINE.json configs[0] at reduced size: synthetic chunks (length mix) -> 12-layer encoder -> flat
+    inner-product index -> top-10 for queries that are re-encoded chunks.  HIP pipeline (bf16 encoder, device index)
+    vs the reference path restated on the CPU (fp32 torch encoder + flat kNN oracle): same ids wherever the
+    reference's own score gap exceeds the encoder tolerance, scores within 1e-3 (north star)."""
+    from oracle import knn_oracle as ko
+    from oracle import mpnet_oracle as mo
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+    from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+
+    cfg = mo.MpnetCfg(num_layers=12)
+    rng = np.random.default_rng(11)
+    lengths = np.clip(np.round(rng.uniform(100, 2000, 160) / 16) + 2, 2, 384).astype(int).tolist()   # short mix: CPU time
+    batch = mo.synth_batch(cfg, lengths, seed=12)
+    ref_emb = mo.encode(mo.synth_weights(cfg, 5), cfg, batch)
+    enc = MpnetEncoder(synthetic_seed=5, compute="bf16")
+    order = sorted(range(len(batch)), key=lambda i: -len(batch[i]))
+    emb = np.empty_like(ref_emb)
+    for s0 in range(0, len(order), 16):                                    # batch 16, length-sorted (src/embeddings.py:33)
+        idx = order[s0:s0 + 16]
+        emb[idx] = enc.encode_ids([batch[i] for i in idx])
+    assert ((emb * ref_emb).sum(1) > 1 - 1e-3).all()
+    ix = IndexFlatIP(768)
+    ix.add(emb, normalize=True)
+    ref = ko.FlatIndexOracle(768, 0)
+    ref.add(ko.normalize_rows(ref_emb))
+    qid = np.arange(0, 160, 8)
+    D, I = ix.search(emb[qid], 10, normalize=True)
+    Dr, Ir = ref.search(ko.normalize_rows(ref_emb[qid]), 10)
+    assert (I[:, 0] == qid).all() and (Ir[:, 0] == qid).all()
+    assert np.abs(D - Dr).max() < 1e-3
+    gaps = np.abs(np.diff(Dr, axis=1))
+    safe = np.ones_like(Ir, dtype=bool)
+    safe[:, 1:] &= gaps > 1e-3
+    safe[:, :-1] &= gaps > 1e-3
+    safe[:, -1] = False
+    assert (I[safe] == Ir[safe]).all()
+    # (synthetic weights make all chunks similar: the top-10 boundary is a near-tie, so compare through the reference's
+    # own scores) every id returned by the HIP pipeline scores within the tolerance of the reference's 10th best
+    full = ko.normalize_rows(ref_emb[qid]) @ ko.normalize_rows(ref_emb).T
+    assert (np.take_along_axis(full, I, axis=1) >= Dr[:, -1:] - 2e-3).all()
+    enc.close()
+    ix.close()

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const TIn* __restrict__ A, 
 // epilogue and bias_tab[h][rel + (maxL-1)] = log2(e) * W_rel[bucket(rel)][h] (rel = key - query):
 // scores live in the log2 domain.
 template <int HD>
-__global__ __launch_bounds__(256) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
+__global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,
                                                         bf16_t* __restrict__ ctx) {
     static_assert(HD == 64, "head_dim 64");

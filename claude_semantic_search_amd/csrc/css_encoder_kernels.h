@@ -730,6 +730,9 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const TIn* __restrict__ A, 
 // tile in LDS through ds_read_b64_tr_b16.  q is pre-scaled by log2(e)/8 in the QKV
 // epilogue and bias_tab[h][rel + (maxL-1)] = log2(e) * W_rel[bucket(rel)][h] (rel = key - query):
 // scores live in the log2 domain.
+// (Measured alternatives: __launch_bounds__(256, 4) -- 120 instead of 150 registers, four blocks per CU -- took this
+// latency-bound kernel from 3.1 to 2.46 ms per batch; a variant with one block per (sequence, head) and three
+// 32-query groups per wave, staging K/V once, needs 239 registers and ran 4.1 ms: occupancy beats reuse here.)
 template <int HD>
 __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,

@@ -468,6 +468,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm(const TIn* __restrict__ A,
 // under it (MI355X_MICROARCH.md, DVFS item 7; measured +8 % on the kNN scan's identical main loop).
 // Accumulator geometry: lane (lq = lane & 15, lg = lane >> 4) holds token row 16 m + lq (m < 8) and the 4
 // consecutive output columns 16 n + 4 lg + {0..3} (n < 4) of the wave's 128 x 64 block.
+// (Tile-count tails -- N = 768 gives 4.5 tiles per CU -- were tried as 128-token half tiles in the last round:
+// no gain, a half tile still moves 3/4 of the stage bytes and the loop is fill bound.)
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                 const float* __restrict__ bias, void* __restrict__ Cout, int M, int N,

@@ -13,12 +13,18 @@ row-partitioned over the ranks (strong scaling); each step ends with one RCCL
 all-gather of the per-shard top-k and a merge.
 
 The JSON line also carries:
-  roofline      dominant kernel of the timed region, measured with HIP events on
-                the launch stream inside this run (css_prof_*).
+  roofline      dominant kernel of the timed region -- the main stage of the search cascade,
+                k_scan_coarse<false,true,..> (bf16 MFMA bound) -- measured with HIP events on the
+                launch stream inside this run (css_prof_*); `traffic` = HBM-side bytes per launch
+                from the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes).
   cpu_baseline  the CPU oracle (kind "port") timed on this box's host cores on a
                 bounded sample of the same workload, rank 0 / N=1 only.
-  extra         single-query (the reference's real call shape) sweep latency and
-                its HBM roofline fraction; encoder throughput when available.
+  extra         nq1_k10 / nq1_k100: single-query search (the reference's real call shape) with the
+                HBM roofline of its main sweep stage; masked_half_rows: the same searches with an
+                allow-bitmap; exact_fp32_mode: the parity mode (every score formed in fp32 by the
+                scan kernels) on the same index; encode: batch-256 x 384 encoder forward with its
+                MFMA roofline, per-kernel times, length-mix and text-path (strings in) runs, CPU
+                baseline and parity against the oracle.
 """
 from __future__ import annotations
 

@@ -1,0 +1,36 @@
+"""Stability soak (development aid): mixed searches and encodes for a few minutes; checks results stay identical
+and device memory does not grow.  python tools/soak.py [seconds]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+from claude_semantic_search_amd.flat_index import IndexFlatIP
+from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+from claude_semantic_search_amd import synth
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+ix = IndexFlatIP(768)
+ix.reserve(4_000_000)
+ix.add_synthetic(4_000_000, seed=7)
+enc = MpnetEncoder(synthetic_seed=1, compute="bf16")
+q = synth.rows(600, 768, 99)
+allow = np.random.default_rng(0).random(4_000_000) < 0.3
+ref = {n: ix.search(q[:n], 10, normalize=True) for n in (1, 3, 8, 40, 600)}
+refm = ix.search(q[:40], 10, normalize=True, allow=allow)
+ids = [list(range(4, 4 + n)) for n in (5, 60, 384, 17)]
+ids = [[0] + s[:382] + [2] for s in ids]
+eref = enc.encode_ids(ids)
+free0 = torch.cuda.mem_get_info()[0]
+t0 = time.time(); it = 0
+while time.time() - t0 < secs:
+    for n in (1, 3, 8, 40, 600):
+        D, I = ix.search(q[:n], 10, normalize=True)
+        assert (I == ref[n][1]).all() and np.array_equal(D, ref[n][0]), f"search nq={n} changed at iteration {it}"
+    D, I = ix.search(q[:40], 10, normalize=True, allow=allow)
+    assert (I == refm[1]).all()
+    e = enc.encode_ids(ids)
+    assert np.array_equal(e, eref), f"encode changed at iteration {it}"
+    it += 1
+    if it % 50 == 0:
+        print(f"iteration {it}, {time.time() - t0:.0f}s, free HBM delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB", flush=True)
+print(f"soak ok: {it} iterations in {time.time() - t0:.0f}s; free HBM delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB")

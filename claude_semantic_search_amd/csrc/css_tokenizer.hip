@@ -7,11 +7,15 @@
 // "<s> ... </s>" + truncation to max_seq_length (src/embeddings.py:97).  A 1.5 kB chunk costs the encoder
 // ~0.1 ms of GPU time and the Python tokenizer ~2 ms, so the text path needs a native front end.
 //
-// This implementation handles texts that are pure ASCII (the bulk of code / chat transcripts) on all host
-// cores; a text containing any byte >= 0x80 is reported back (len = -1) and tokenised by the Python
-// implementation of the same pipeline (claude_semantic_search_amd/tokenizer.py), which is what pins the
-// Unicode rules (NFD, general categories) against transformers in tests/test_tokenizer.py.
+// Texts are tokenised on all host cores.  Pure-ASCII texts (the bulk of code / chat transcripts) take a byte
+// loop; other texts are decoded from UTF-8 and pushed through per-code-point tables generated from Python's
+// unicodedata (css_unicode_tables.h, tools/gen_unicode_tables.py: dropped / separator / punctuation / CJK /
+// NFD-stripped-lower-cased sequence), Hangul syllables are decomposed algorithmically.  What the tables cannot
+// express is reported back (len = -1) and tokenised by the Python implementation of the same pipeline
+// (claude_semantic_search_amd/tokenizer.py): invalid UTF-8, a capital sigma (str.lower()'s final-sigma rule needs
+// context), and any non-ASCII text when lower-casing is off.  tests/test_tokenizer.py checks every code point.
 #include "css_common.h"
+#include "css_unicode_tables.h"
 
 #include <algorithm>
 #include <fstream>
@@ -96,6 +100,147 @@ void encode_ascii(const css_tokenizer& t, const char* s, int64_t n, int budget, 
     if ((int)out.size() > budget) out.resize(budget);
 }
 
+// one UTF-8 text (lower-casing pipeline) -> ids; false: the text needs the Python implementation
+bool encode_utf8(const css_tokenizer& t, const char* s, int64_t n, int budget, std::vector<int32_t>& out,
+                 std::string& word, std::vector<int>& offs, std::string& key) {
+    using namespace css_uni;
+    out.clear();
+    word.clear();
+    offs.clear();
+    auto push_char = [&](uint32_t cp) {
+        offs.push_back((int)word.size());
+        if (cp < 0x80) {
+            word.push_back((char)cp);
+        } else if (cp < 0x800) {
+            word.push_back((char)(0xC0 | (cp >> 6)));
+            word.push_back((char)(0x80 | (cp & 63)));
+        } else if (cp < 0x10000) {
+            word.push_back((char)(0xE0 | (cp >> 12)));
+            word.push_back((char)(0x80 | ((cp >> 6) & 63)));
+            word.push_back((char)(0x80 | (cp & 63)));
+        } else {
+            word.push_back((char)(0xF0 | (cp >> 18)));
+            word.push_back((char)(0x80 | ((cp >> 12) & 63)));
+            word.push_back((char)(0x80 | ((cp >> 6) & 63)));
+            word.push_back((char)(0x80 | (cp & 63)));
+        }
+    };
+    auto flush_word = [&]() {
+        const int nch = (int)offs.size();
+        if (nch == 0) return;
+        if (nch > t.max_chars) {
+            out.push_back(t.unk);
+        } else {
+            offs.push_back((int)word.size());
+            const size_t first = out.size();
+            int start = 0;
+            bool bad = false;
+            while (start < nch) {
+                int end = nch;
+                int32_t cur = -1;
+                while (start < end) {
+                    key.clear();
+                    if (start > 0) key.append("##");
+                    key.append(word, offs[start], offs[end] - offs[start]);
+                    auto it = t.vocab.find(key);
+                    if (it != t.vocab.end()) {
+                        cur = it->second;
+                        break;
+                    }
+                    --end;
+                }
+                if (cur < 0) {
+                    bad = true;
+                    break;
+                }
+                out.push_back(cur);
+                start = end;
+            }
+            if (bad) {
+                out.resize(first);
+                out.push_back(t.unk);
+            }
+        }
+        word.clear();
+        offs.clear();
+    };
+    auto emit_punct = [&](uint32_t cp) {
+        flush_word();
+        push_char(cp);
+        key.assign(word);
+        word.clear();
+        offs.clear();
+        auto it = t.vocab.find(key);
+        out.push_back(it != t.vocab.end() ? it->second : t.unk);
+    };
+    int64_t i = 0;
+    while (i < n && (int)out.size() < budget) {
+        uint32_t cp;
+        const unsigned char c0 = (unsigned char)s[i];
+        if (c0 < 0x80) {
+            cp = c0;
+            i += 1;
+        } else if (c0 >= 0xC2 && c0 <= 0xDF && i + 1 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80) {
+            cp = ((c0 & 0x1F) << 6) | ((unsigned char)s[i + 1] & 0x3F);
+            i += 2;
+        } else if (c0 >= 0xE0 && c0 <= 0xEF && i + 2 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 &&
+                   ((unsigned char)s[i + 2] & 0xC0) == 0x80) {
+            cp = ((c0 & 0x0F) << 12) | (((unsigned char)s[i + 1] & 0x3F) << 6) | ((unsigned char)s[i + 2] & 0x3F);
+            if (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF)) return false;  // overlong / surrogate: not valid UTF-8
+            i += 3;
+        } else if (c0 >= 0xF0 && c0 <= 0xF4 && i + 3 < n && ((unsigned char)s[i + 1] & 0xC0) == 0x80 &&
+                   ((unsigned char)s[i + 2] & 0xC0) == 0x80 && ((unsigned char)s[i + 3] & 0xC0) == 0x80) {
+            cp = ((c0 & 0x07) << 18) | (((unsigned char)s[i + 1] & 0x3F) << 12) | (((unsigned char)s[i + 2] & 0x3F) << 6) |
+                 ((unsigned char)s[i + 3] & 0x3F);
+            if (cp < 0x10000 || cp > 0x10FFFF) return false;
+            i += 4;
+        } else {
+            return false;
+        }
+        if (cp < 0x80) {  // the ASCII rules of encode_ascii
+            if (cp == ' ' || cp == '\t' || cp == '\n' || cp == '\r') flush_word();
+            else if (cp < 0x20 || cp == 0x7F) continue;
+            else if (ascii_punct((unsigned char)cp)) emit_punct(cp);
+            else push_char(cp >= 'A' && cp <= 'Z' ? cp + 32 : cp);
+            continue;
+        }
+        if (cp == 0x03A3) return false;  // capital sigma: lower() depends on the position in the word
+        switch (kPages[kPageIndex[cp >> 8]][cp & 255]) {
+            case C_CHAR: push_char(cp); break;
+            case C_DROP: break;
+            case C_SPACE: flush_word(); break;
+            case C_PUNCT: emit_punct(cp); break;
+            case C_CJK:
+                flush_word();
+                push_char(cp);
+                flush_word();
+                break;
+            case C_HANGUL: {
+                const uint32_t si = cp - 0xAC00;
+                push_char(0x1100 + si / 588);
+                push_char(0x1161 + (si % 588) / 28);
+                if (si % 28) push_char(0x11A7 + si % 28);
+                break;
+            }
+            default: {  // C_MAP
+                const uint32_t* kb = kMapKeys;
+                const uint32_t* it = std::lower_bound(kb, kb + kMapCount, cp);
+                if (it == kb + kMapCount || *it != cp) return false;  // (cannot happen: the class says it is mapped)
+                const int idx = (int)(it - kb);
+                for (int j = 0; j < kMapLen[idx]; ++j) {
+                    const uint32_t e = kMapPool[kMapOff[idx] + j], kind = e >> 30, ocp = e & 0x3FFFFFFFu;
+                    if (kind == K_CHAR) push_char(ocp);
+                    else if (kind == K_SPACE) flush_word();
+                    else emit_punct(ocp);
+                }
+            }
+        }
+    }
+    if ((int)out.size() < budget) flush_word();
+    if ((int)out.size() > budget) out.resize(budget);
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -149,6 +294,7 @@ int css_tokenizer_encode_batch(const css_tokenizer* t, const char* bytes, const 
     nt = (int)std::min<int64_t>(nt, n);
     auto work = [&](int64_t lo, int64_t hi) {
         std::vector<int32_t> ids;
+        std::vector<int> offs;
         std::string word, key;
         for (int64_t i = lo; i < hi; ++i) {
             const char* s = bytes + offsets[i];
@@ -160,11 +306,12 @@ int css_tokenizer_encode_batch(const css_tokenizer* t, const char* bytes, const 
                     break;
                 }
             int32_t* row = ids_out + (size_t)i * max_len;
-            if (!ascii) {
-                lens_out[i] = -1;  // the caller tokenises this text with the Unicode-complete implementation
+            if (ascii) {
+                encode_ascii(*t, s, len, max_len - 2, ids, word, key);
+            } else if (!t->lower || !encode_utf8(*t, s, len, max_len - 2, ids, word, offs, key)) {
+                lens_out[i] = -1;  // the caller tokenises this text with the Python implementation
                 continue;
             }
-            encode_ascii(*t, s, len, max_len - 2, ids, word, key);
             int p = 0;
             row[p++] = t->bos;
             for (int32_t v : ids) row[p++] = v;

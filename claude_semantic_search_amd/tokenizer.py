@@ -164,9 +164,11 @@ class FastWordPieceTokenizer(WordPieceTokenizer):
 
 
 class NativeWordPieceTokenizer(WordPieceTokenizer):
-    """Batch front end on the C++ tokenizer of libcss_hip.so (``css_tokenizer_*``, all host cores): pure-ASCII
-    texts are tokenised natively, texts with non-ASCII characters by the Unicode-complete implementation
-    (``FastWordPieceTokenizer`` when the HF library is importable, else this class's Python code)."""
+    """Batch front end on the C++ tokenizer of libcss_hip.so (``css_tokenizer_*``, all host cores).  The library
+    handles ASCII and UTF-8 texts through tables generated from this module's own rules
+    (``tools/gen_unicode_tables.py``); what it reports back -- invalid UTF-8, texts with a capital sigma (final-sigma
+    rule of ``str.lower``), non-ASCII text with lower-casing off -- is tokenised by this class's Python code, so both
+    halves follow one specification.  ``last_fallbacks`` counts the texts of the last batch that took that route."""
 
     def __init__(self, vocab_path: str, lower: bool = True):
         super().__init__(vocab_path, lower)
@@ -178,10 +180,7 @@ class NativeWordPieceTokenizer(WordPieceTokenizer):
         h = ctypes.c_void_p()
         nat.check(nat.lib().css_tokenizer_create(str(vocab_path).encode(), 1 if lower else 0, ctypes.byref(h)))
         self._h = h
-        try:
-            self._uni: Optional[WordPieceTokenizer] = FastWordPieceTokenizer(vocab_path, lower)
-        except ImportError:
-            self._uni = None
+        self.last_fallbacks = 0
 
     def __del__(self):  # pragma: no cover
         try:
@@ -212,13 +211,9 @@ class NativeWordPieceTokenizer(WordPieceTokenizer):
                                                                    ids.ctypes.data, lens.ctypes.data, 0))
         out = [ids[i, : lens[i]] if lens[i] >= 0 else None for i in range(n)]
         rest = [i for i in range(n) if lens[i] < 0]
-        if rest:
-            if self._uni is not None:
-                enc = self._uni.encode_batch([texts[i] for i in rest], max_len)
-            else:
-                enc = [WordPieceTokenizer.encode(self, texts[i], max_len) for i in rest]
-            for i, e in zip(rest, enc):
-                out[i] = np.asarray(e, dtype=np.int32)
+        self.last_fallbacks = len(rest)
+        for i in rest:
+            out[i] = np.asarray(WordPieceTokenizer.encode(self, texts[i], max_len), dtype=np.int32)
         return out
 
 

@@ -186,8 +186,9 @@ int css_mpnet_rel_bucket(int rel, int num_buckets, int max_distance);
  * vocab.txt in HF layout (one piece per line, id = line number).  encode_batch:
  * `bytes` holds the n UTF-8 texts back to back, text i = [offsets[i], offsets[i+1]);
  * ids_out is [n, max_len] (padded with <pad>), lens_out[i] the token count incl.
- * <s> and </s>, or -1 for a text with non-ASCII bytes, which the caller tokenises with
- * the Unicode-complete Python implementation of the same pipeline.  nthreads <= 0: all cores. */
+ * <s> and </s>, or -1 for a text the tables cannot express (invalid UTF-8, a capital
+ * sigma, non-ASCII text with lower-casing off), which the caller tokenises with the
+ * Python implementation of the same pipeline.  nthreads <= 0: all cores. */
 typedef struct css_tokenizer css_tokenizer;
 int css_tokenizer_create(const char* vocab_path, int lowercase, css_tokenizer** out);
 int css_tokenizer_free(css_tokenizer* t);

@@ -93,3 +93,29 @@ def test_wordpiece_pipeline_matches_transformers_mpnet_tokenizer(tmp_path):
     got = fast.encode_batch(texts + ascii_only, 64)
     assert [g.tolist() for g in got] == want + [hf(t, truncation=True, max_length=64)["input_ids"] for t in ascii_only]
     assert fast.encode("Hello, World", 8) == hf("Hello, World", truncation=True, max_length=8)["input_ids"]
+
+
+def test_native_tokenizer_follows_the_python_rules_for_every_code_point(tmp_path):
+    """The C++ tables (tools/gen_unicode_tables.py) against the Python implementation they were generated from:
+    every BMP code point and a sample of the astral planes, embedded in a word and standing alone."""
+    from claude_semantic_search_amd.tokenizer import NativeWordPieceTokenizer
+
+    rng = random.Random(3)
+    vocab_path, words = _synthetic_vocab(tmp_path, rng)
+    extra = ["ab", "cd", "##cd", "##ab", "σ", "ς", "##σ", "ᄀ", "##ᅡ", "##ᆨ", "i", "ss", "ω", "a", "##a", "中", "。", "！"]
+    with open(vocab_path, "a", encoding="utf-8") as f:
+        f.write("\n".join(extra) + "\n")
+    py = WordPieceTokenizer(vocab_path)
+    nat = NativeWordPieceTokenizer(vocab_path)
+    cps = [c for c in list(range(0x80, 0x10000)) + list(range(0x10000, 0x110000, 37)) if not 0xD800 <= c <= 0xDFFF]
+    texts = ["ab" + chr(c) + "cd " + chr(c) for c in cps]
+    got = nat.encode_batch(texts, 16)
+    assert nat.last_fallbacks == 1                      # U+03A3 only (final-sigma rule stays in Python)
+    bad = [hex(c) for c, t, g in zip(cps, texts, got) if g.tolist() != py.encode(t, 16)]
+    assert not bad, bad[:20]
+    # mixed sentences, truncation, long words, invalid UTF-8 (lone surrogate) through the fallback
+    sents = [_random_text(rng, words) + rng.choice(["", " 가각 한국어", " Ünïcödé Σίσυφος", " 日本語のテキスト", " a\u0301b e\u0308"]) for _ in range(400)]
+    sents += ["\ud800 lone surrogate", "x" * 99 + "é" * 2, "é" * 101, ""]
+    got = nat.encode_batch(sents, 48)
+    assert [g.tolist() for g in got] == [py.encode(t, 48) for t in sents]
+    assert nat.last_fallbacks >= 1

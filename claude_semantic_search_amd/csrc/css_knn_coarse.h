@@ -68,7 +68,7 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
 #define CZ_QOFF(M_) (MS * (M_) + lq)
 #define CZ_ROFF(N_, R_) (MS == 32 ? 32 * (N_) + ((R_) & 3) + 8 * ((R_) >> 2) + 4 * lg : 16 * (N_) + 4 * lg + (R_))
 #define CZ_EPILOGUE()                                                                                        \
-            const int64_t tile = tile_of(ct_tile);                                                                     \
+            const int64_t tile = CZ_TILE_OF(ct_tile);                                                                  \
             const int64_t row0 = tile * CZ_T + wc * 64;                                                                \
             if (xn2 != nullptr) { /* L2: score = 2 x.q - ||x||^2 (||q||^2 is the same for every row of a query) */ \
 _Pragma("unroll")                                                                                                      \
@@ -100,6 +100,9 @@ _Pragma("unroll")                                                               
                         }                                                                                              \
                 }                                                                                                      \
             } else {                                                                                                   \
+                float thr_m[TM];                                                                                       \
+_Pragma("unroll")                                                                                                      \
+                for (int m = 0; m < TM; ++m) thr_m[m] = sthr[wr * 128 + CZ_QOFF(m)];                                   \
                 bool any = false;                                                                                      \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m)                                                                           \
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      const float* __restrict__ xn2, int dbg_arg) {
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
-    // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads
+    // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads, bit5 half of the LDS reads
     const int dbg = DBG ? dbg_arg : 0;
     static_assert(MS == 32 || MS == 16, "MFMA shape: 32x32x16 or 16x16x32");
     constexpr int NW = 8, WN = 4, TM = 128 / MS, TN = 64 / MS, NR = MS == 32 ? 16 : 4;
@@ -178,9 +181,11 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     const int total = my_ntiles * KT;
     if (total == 0) return;
 
-    float thr_m[TM];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) thr_m[m] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + wr * 128 + CZ_QOFF(m)];
+    // the block's 256 thresholds wait in LDS (a separate object from the DMA ring) and are read in the epilogue:
+    // keeping them in registers through the main loop pushed the DMA source pointers into scratch
+    __shared__ float sthr[CZ_T];
+    if (tid < CZ_T) sthr[tid] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
+    __syncthreads();
 
     // Sibling pacing (speed only, never needed for correctness): the nqt blocks that walk the same row tiles
     // drift apart (appends, DMA jitter); once they are more than ~2 K-steps apart the tile's rows have left
@@ -205,23 +210,21 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         dst[i] = (isA ? 0 : A_BYTES) + (isA ? piece : piece - 32) * 1024;
         if (isA) src[i] = reinterpret_cast<const char*>(qh + (size_t)(qtile * CZ_T + trow) * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);
     }
-    auto tile_of = [&](int ti) -> int64_t {
-        const int64_t u = u0 + (int64_t)ti * ustep;
-        return (STAGE0 ? u : u + u / gm1 + 1) * stride;  // the multiples of the growth factor belong to earlier stages
-    };
-    auto set_src = [&](int ti) {
-        const int64_t r0 = tile_of(ti) * CZ_T;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int piece = wave + NW * i;
-            if (piece >= 32) {
-                const int trow = (piece - 32) * 8 + prow;
-                int64_t grow = r0 + trow;
-                grow = grow < ntotal ? grow : ntotal - 1;
-                src[i] = reinterpret_cast<const char*>(xh + (size_t)grow * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);
-            }
-        }
-    };
+// (macros, not lambdas: a by-reference capture of src[] leaves the array in scratch once register pressure rises)
+#define CZ_TILE_OF(TI_) ((STAGE0 ? (u0 + (int64_t)(TI_) * ustep) : (u0 + (int64_t)(TI_) * ustep) + (u0 + (int64_t)(TI_) * ustep) / gm1 + 1) * stride)
+#define CZ_SET_SRC(TI_)                                                                                              \
+    {                                                                                                                \
+        const int64_t r0_ = CZ_TILE_OF(TI_) * CZ_T; /* multiples of the growth factor belong to earlier stages */     \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                            \
+            const int piece = wave + NW * i;                                                                         \
+            if (piece >= 32) {                                                                                       \
+                const int trow = (piece - 32) * 8 + prow;                                                            \
+                int64_t grow = r0_ + trow;                                                                           \
+                grow = grow < ntotal ? grow : ntotal - 1;                                                            \
+                src[i] = reinterpret_cast<const char*>(xh + (size_t)grow * K) + ((pchunk ^ ((trow >> 1) & 7)) << 4);  \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
 #define CZ_ISSUE(KT_, SLOT_)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                                \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(KT_) * CZ_RB), \
@@ -237,14 +240,14 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
             for (int r = 0; r < NR; ++r) acc[m][n][r] = 0.f;
 
     int it_tile = 0, it_kt = 0, gi = 0;
-    set_src(0);
+    CZ_SET_SRC(0)
     if (!(dbg & 4)) {
         CZ_ISSUE(0, 0)
     }
     gi = 1;
     if (++it_kt == KT) {
         it_kt = 0;
-        if (++it_tile < my_ntiles) set_src(it_tile);
+        if (++it_tile < my_ntiles) CZ_SET_SRC(it_tile)
     }
     int ct_tile = 0, kt = 0;
     for (int g = 0; g < total; ++g) {
@@ -267,18 +270,23 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
             }
         }
         __builtin_amdgcn_s_barrier();  // stage g landed for every wave; the slot of stage g-1 is free
-        if (gi < total) {
-            if (!(dbg & 4)) {
-                CZ_ISSUE(it_kt, gi & 1)
-            }
-            ++gi;
-            if (++it_kt == KT) {
-                it_kt = 0;
-                if (++it_tile < my_ntiles) set_src(it_tile);
-            }
-        }
         const char* Ab = smem + (g & 1) * CZ_STAGE;
         const char* Bb = Ab + A_BYTES;
+// the DMA of stage g+1 (into the other slot); ISSUE_FIRST: before this step's fragment reads, else after the first ones
+#define CZ_ISSUE_NEXT()                                                  \
+        if (gi < total) {                                                \
+            if (!(dbg & 4)) {                                            \
+                CZ_ISSUE(it_kt, gi & 1)                                  \
+            }                                                            \
+            ++gi;                                                        \
+            if (++it_kt == KT) {                                         \
+                it_kt = 0;                                               \
+                if (++it_tile < my_ntiles) CZ_SET_SRC(it_tile)           \
+            }                                                            \
+        }
+        if constexpr (DBG) {
+            CZ_ISSUE_NEXT()
+        }
         // C_: 16-wide k step 0..3 (MS = 32: chunk 2 C_ + lg) or 32-wide k step 0..1 (MS = 16: chunk 4 C_ + lg)
 #define CZ_READ(A_, B_, C_)                                                                                            \
     _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                                    \
@@ -300,17 +308,52 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         if constexpr (!DBG) {
             // (explicitly double-buffered fragment reads pinned with sched_barrier measured 2 % slower than
             // hipcc's own read / wait / 4-MFMA groups: LDS latency is not what bounds this loop)
+            // the first fragment reads go out right behind the barrier, the 8 DMA instructions of the next stage
+            // (slow to issue) follow while those reads are in flight
+            {   // (first k-step in two halves of the query tiles: fewer fragments live across the DMA issue)
+                constexpr int CM = (MS == 32 ? 2 : 4);  // chunk index multiplier of this MFMA shape
+                v4f b[TN], a[TM / 2];
 #pragma unroll
-            for (int c = 0; c < (MS == 32 ? 4 : 2); ++c) {
+                for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + cz_swz(wc * 64 + MS * n + lq, lg));
+#pragma unroll
+                for (int m = 0; m < TM / 2; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + MS * m + lq, lg));
+                __builtin_amdgcn_sched_barrier(0);
+                CZ_ISSUE_NEXT()
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1) {
+#pragma unroll
+                        for (int m = 0; m < TM / 2; ++m)
+                            a[m] = *reinterpret_cast<const v4f*>(Ab + cz_swz(wr * 128 + MS * (TM / 2 + m) + lq, lg));
+                    }
+#pragma unroll
+                    for (int m = 0; m < TM / 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) {
+                            if constexpr (MS == 32)
+                                acc[h * (TM / 2) + m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(v8bf, b[n]), __builtin_bit_cast(v8bf, a[m]), acc[h * (TM / 2) + m][n], 0, 0, 0);
+                            else
+                                acc[h * (TM / 2) + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(v8bf, b[n]), __builtin_bit_cast(v8bf, a[m]), acc[h * (TM / 2) + m][n], 0, 0, 0);
+                        }
+                }
+                (void)CM;
+            }
+#pragma unroll
+            for (int c = 1; c < (MS == 32 ? 4 : 2); ++c) {
                 v4f a[TM], b[TN];
                 CZ_READ(a, b, c)
                 CZ_MFMA(a, b)
             }
         } else if (!(dbg & 2)) {
+            v4f a[TM], b[TN];
 #pragma unroll
             for (int c = 0; c < (MS == 32 ? 4 : 2); ++c) {
-                v4f a[TM], b[TN];
-                if (!(dbg & 16)) {
+                if ((dbg & 32) && (c & 1)) {
+                    // bit5: odd k-steps reuse the previous fragments (half the LDS read traffic; wrong results)
+                } else if (!(dbg & 16)) {
                     CZ_READ(a, b, c)
                 } else {
 #pragma unroll
@@ -330,6 +373,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         }
 #undef CZ_READ
 #undef CZ_MFMA
+#undef CZ_ISSUE_NEXT
         if (++kt == KT) {
             CZ_EPILOGUE();
             kt = 0;
@@ -337,6 +381,8 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
         }
     }
 #undef CZ_ISSUE
+#undef CZ_SET_SRC
+#undef CZ_TILE_OF
 }
 
 // The same cascade stage for 1..4 queries: an HBM-bound sweep over the bf16 shadow rows (half the bytes of the

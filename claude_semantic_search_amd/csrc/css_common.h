@@ -40,6 +40,8 @@ struct DeviceGuard {
 };
 
 int check_device(int device);  // CSS_OK or CSS_ERR_NO_DEVICE / CSS_ERR_INVALID
+// hipFuncAttributeMaxDynamicSharedMemorySize for (kernel, device), set once (thread safe)
+int ensure_dynamic_lds(const void* kernel, size_t bytes, int device);
 bool prof_enabled();
 
 }  // namespace css

@@ -47,6 +47,19 @@ int check_device(int device) {
     return CSS_OK;
 }
 
+int ensure_dynamic_lds(const void* kernel, size_t bytes, int device) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(kernel, device);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return CSS_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", __FILE__, __LINE__);
+    done[key] = bytes;
+    return CSS_OK;
+}
+
 // ---------------------------------------------------------------- profiling
 struct ProfRec {
     hipEvent_t a, b;

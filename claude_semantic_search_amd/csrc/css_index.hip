@@ -47,6 +47,7 @@ struct css_index {
     float* xnorm2 = nullptr;
     unsigned short* xh = nullptr;  // bf16 shadow rows [cap][dpad] for the coarse scan (nullptr: not kept)
     int shadow = -1;               // -1 undecided, 0 off, 1 on (CSS_KNN_SHADOW, HBM headroom)
+    int shadow_policy = -1;        // css_index_set_shadow: -1 automatic, 0 never, 1 always
     int search_mode = CSS_SEARCH_AUTO;
     const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
     uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
@@ -70,6 +71,13 @@ struct css_index {
     float* cand_s = nullptr;  size_t cand_s_cap = 0;
     uint32_t* cand_i = nullptr; size_t cand_i_cap = 0;
     int* cpace = nullptr;     size_t cpace_cap = 0;     // sibling pacing counters [stage][group]
+    // device-side exact fix-up of flagged queries (k_scan_small<FIX>): one global list + lock per query
+    float* fix_s = nullptr;   uint32_t* fix_i = nullptr; size_t fix_cap = 0;    // entries [nq_pad][k]
+    int* fix_lock = nullptr;  size_t fix_lock_cap = 0;
+    // rows written by css_index_add_dev / _add_synthetic on the CALLER's stream: searches, reallocation and
+    // export wait for this event before touching rows, norms or maxn2
+    hipEvent_t ingest_ev = nullptr;
+    bool ingest_pending = false;
     std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
     std::mutex ws_mu;      // workspaces + own stream are single-user
 };
@@ -135,13 +143,22 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
 // Block = 4 waves.  A wave instruction covers 4 rows: lane = 16*r + sub reads the
 // float4 at column 64*t + 4*sub of row r, so 16 lanes fetch 256 contiguous bytes.
 // Scores are "larger is better": IP -> dot, L2 -> -(sum (x-q)^2).
-// LDS: qs[NQ][dpad] | ls[NQ][k] | li[NQ][k] | lock[NQ]
-template <int NQ, int TT, int METRIC>
+// LDS: qs[NQ][dpad] | ls[NQ][k] | li[NQ][k] | lock[NQ] | qid[NQ] | (FIX) per-wave merge scratch
+//
+// FIX = true is the device-side exact fix-up of the candidate path (css_knn_coarse.h): the launch follows
+// every cascade unconditionally, reads the number of flagged queries from device memory and returns at once
+// when it is zero (the usual case) -- no host round trip.  Otherwise the grid walks the flagged queries NQ at
+// a time; a block's lists are merged into one global list per query under an agent-scope lock (release /
+// acquire fences around plain loads and stores, MI355X_MICROARCH.md "Valid forms"); the lists were reset by
+// the kernel that flagged the query and k_fix_write turns them into D / I rows afterwards.
+template <int NQ, int TT, int METRIC, bool FIX = false>
 __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict__ xb, const float* __restrict__ qpad,
                                                     int64_t ntotal, int T_rt, int k, int64_t groups_per_block,
                                                     int* __restrict__ gthr, float* __restrict__ part_s,
-                                                    uint32_t* __restrict__ part_i, int nq_real,
-                                                    const uint32_t* __restrict__ mask) {
+                                                    uint32_t* __restrict__ part_i, int nq_real_arg,
+                                                    const uint32_t* __restrict__ mask,
+                                                    const int* __restrict__ flag_list, const int* __restrict__ nflag_p,
+                                                    float* fix_s, uint32_t* fix_i, int* fix_lock) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = TT > 0 ? TT : T_rt;  // float4 steps of 16 lanes: dpad = 64*T
     const int dpad = T * 64;
@@ -149,16 +166,30 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
     float* ls = qs + NQ * dpad;
     uint32_t* li = reinterpret_cast<uint32_t*>(ls + NQ * k);
     int* lock = reinterpret_cast<int*>(li + NQ * k);
+    int* qid = lock + NQ;                                   // query served by list j
+    float* ms = reinterpret_cast<float*>(qid + NQ);         // FIX: [4 waves][k] merge scratch
+    uint32_t* mi = reinterpret_cast<uint32_t*>(ms + 4 * k);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, rsub = lane >> 4;
+    const int nfl = FIX ? __hip_atomic_load(nflag_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+    if (FIX && nfl == 0) return;
 
-    for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq_real ? qpad[i] : 0.f;
+  for (int c0 = 0; c0 < (FIX ? nfl : 1); c0 += NQ) {
+    const int nq_real = FIX ? min(NQ, nfl - c0) : nq_real_arg;
+    if (tid < NQ) {
+        lock[tid] = 0;
+        qid[tid] = FIX ? (tid < nq_real ? flag_list[c0 + tid] : 0) : tid;
+    }
+    __syncthreads();
+    for (int i = tid; i < NQ * dpad; i += 256) {
+        const int j = i / dpad;
+        qs[i] = j < nq_real ? qpad[(size_t)qid[j] * dpad + (i - j * dpad)] : 0.f;
+    }
     for (int i = tid; i < NQ * k; i += 256) {
         ls[i] = -INFINITY;
         li[i] = kInvalidRow;
     }
-    if (tid < NQ) lock[tid] = 0;
     __syncthreads();
 
     const float4* qs4 = reinterpret_cast<const float4*>(qs);
@@ -177,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
         if ((iter & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
-                gcache[j] = key2f(__hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                gcache[j] = key2f(__hip_atomic_load(&gthr[qid[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
 
         const int64_t row = g * 4 + rsub;
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
 #pragma unroll
             for (int u = 1; u < NQ; ++u) s = j == u ? sc[u] : s;
             const float lthr = ls[j * k + (k - 1)];
-            const float gj = key2f(__hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float gj = key2f(__hip_atomic_load(&gthr[qid[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const bool pass = valid && sub == 0 && s >= lthr && s >= gj;
             unsigned long long m = __ballot(pass);
             if (m == 0ull) continue;
@@ -283,18 +314,97 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
             const float kth = ls[j * k + (k - 1)];
             if (lane == 0) {
                 atomicExch(&lock[j], 0);
-                if (changed && kth > gj) atomicMax(&gthr[j], f2key(kth));
+                if (changed && kth > gj) atomicMax(&gthr[qid[j]], f2key(kth));
             }
         }
     }
     __syncthreads();
-    // part layout: [q][block][k]
-    const int G = gridDim.x;
-    for (int i = tid; i < nq_real * k; i += 256) {
-        const int j = i / k, p = i - j * k;
-        const size_t o = ((size_t)j * G + blockIdx.x) * k + p;
-        part_s[o] = ls[i];
-        part_i[o] = li[i];
+    if constexpr (FIX) {
+        // merge this block's lists into the global list of each query (rare path: clarity over speed)
+        float* ws = ms + wave * k;
+        uint32_t* wi = mi + wave * k;
+        for (int j = wave; j < nq_real; j += kWaves) {
+            const int q = qid[j];
+            float* gs = fix_s + (size_t)q * k;
+            uint32_t* gi = fix_i + (size_t)q * k;
+            if (li[j * k] == kInvalidRow) continue;  // nothing found in this block's rows (wave uniform)
+            // a lower bound of the global k-th best: lists only improve, so a stale value only merges more
+            const float gk = key2f(__hip_atomic_load(&gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (ls[j * k] < gk) continue;
+            if (lane == 0) {
+                int expect = 0;
+                while (!__hip_atomic_compare_exchange_strong(&fix_lock[q], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                    expect = 0;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = lane; i < k; i += 64) {
+                ws[i] = gs[i];
+                wi[i] = gi[i];
+            }
+            bool changed = false;
+            for (int p = 0; p < k; ++p) {
+                const uint32_t id = li[j * k + p];
+                if (id == kInvalidRow) break;
+                if (!wave_insert<uint32_t>(ws, wi, k, ls[j * k + p], id, lane)) break;  // sorted: the rest is worse
+                changed = true;
+            }
+            if (changed) {
+                for (int i = lane; i < k; i += 64) {
+                    gs[i] = ws[i];
+                    gi[i] = wi[i];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float kth = ws[k - 1];
+            if (lane == 0) {
+                if (changed && wi[k - 1] != kInvalidRow) atomicMax(&gthr[q], f2key(kth));
+                __hip_atomic_store(&fix_lock[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();  // the next chunk re-initialises the LDS lists
+    } else {
+        // part layout: [q][block][k]
+        const int G = gridDim.x;
+        for (int i = tid; i < nq_real * k; i += 256) {
+            const int j = i / k, p = i - j * k;
+            const size_t o = ((size_t)j * G + blockIdx.x) * k + p;
+            part_s[o] = ls[i];
+            part_i[o] = li[i];
+        }
+    }
+  }
+}
+
+// Fix-up output: D / I rows of the flagged queries from their global lists (k_scan_small<FIX>).
+template <int METRIC>
+__global__ __launch_bounds__(64) void k_fix_write(const int* __restrict__ flag_list, const int* __restrict__ nflag_p,
+                                                  const float* __restrict__ fix_s, const uint32_t* __restrict__ fix_i,
+                                                  int k, int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I) {
+    const int nfl = *nflag_p;
+    for (int f = blockIdx.x; f < nfl; f += gridDim.x) {
+        const int q = flag_list[f];
+        for (int i = threadIdx.x; i < k; i += 64) {
+            const uint32_t id = fix_i[(size_t)q * k + i];
+            const float s = fix_s[(size_t)q * k + i];  // IP: dot; L2: -(squared distance)
+            const bool ok = id != kInvalidRow;
+            D[(size_t)q * k + i] = METRIC == CSS_METRIC_IP ? (ok ? s : -FLT_MAX) : (ok ? -s : FLT_MAX);
+            I[(size_t)q * k + i] = ok ? id_base + (int64_t)id : (int64_t)-1;
+        }
+    }
+}
+
+// Empty index: every slot padded (cannot be reached through the reference: src/storage.py:421-422).
+__global__ void k_fill_pad(float* __restrict__ D, int64_t* __restrict__ I, int64_t n, float pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        D[i] = pad;
+        I[i] = -1;
     }
 }
 
@@ -839,7 +949,8 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
                                                      const uint32_t* __restrict__ part_i, int G, int k,
                                                      const int* __restrict__ gthr, const float* __restrict__ qnorm2,
                                                      int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
-                                                     int l2_expanded) {
+                                                     int l2_expanded, float* __restrict__ cs_out,
+                                                     uint32_t* __restrict__ ci_out, int* __restrict__ cn_out) {
     __shared__ float fs[CSS_MAX_K];
     __shared__ uint32_t fi[CSS_MAX_K];
     __shared__ float cs[kMergeCap];
@@ -944,6 +1055,17 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
         }
         __syncthreads();
     }
+    if (cs_out != nullptr) {
+        // candidate-path caller (launch_scan_split_rescore): the k best scan scores, in the scan's own form, become
+        // the query's candidate buffer for k_coarse_select<FINAL>
+        for (int i = tid; i < k; i += 256) {
+            const uint32_t id = fi[i];
+            cs_out[(size_t)q * CZ_CAP + i] = id == kInvalidRow ? -INFINITY : fs[i];
+            ci_out[(size_t)q * CZ_CAP + i] = id;
+        }
+        if (tid == 0) cn_out[q] = k;
+        return;
+    }
     for (int i = tid; i < k; i += 256) {
         const uint32_t id = fi[i];
         float s = fs[i];
@@ -1004,9 +1126,13 @@ __global__ void k_fill_int(int* p, int n, int v) {
 bool want_shadow(css_index* ix, int64_t ncap) {
     if (ix->shadow == 0) return false;
     if (ix->dpad % 64 != 0) return false;
-    const char* e = getenv("CSS_KNN_SHADOW");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
+    static const int env_policy = [] {
+        const char* e = getenv("CSS_KNN_SHADOW");
+        return (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : -1);
+    }();
+    const int policy = ix->shadow_policy >= 0 ? ix->shadow_policy : env_policy;
+    if (policy == 0) return false;
+    if (policy == 1) return true;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
     return (double)ncap * ix->dpad * 6.0 <= 0.8 * (double)tot;
@@ -1033,6 +1159,7 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
         }
     }
     if (ix->ntotal > 0) {
+        if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
         CSS_HIP_TRY(hipMemcpyAsync(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float),
                                    hipMemcpyDeviceToDevice, ix->stream));
         CSS_HIP_TRY(hipMemcpyAsync(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
@@ -1086,31 +1213,61 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
     return CSS_OK;
 }
 
-template <int NQ, int TT, int METRIC>
-int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, int G,
-                        int64_t groups_per_block, hipStream_t st) {
+// ---- environment switches (experiments and verification): read once, never written afterwards
+struct KnnEnv {
+    int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
+    int growth = 4;       // CSS_KNN_GROWTH=8: growth factor of the nested row sample
+    int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
+    int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
+    int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
+};
+const KnnEnv& knn_env() {
+    static const KnnEnv env = [] {
+        KnnEnv e;
+        if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
+        if (const char* m = getenv("CSS_KNN_GROWTH")) e.growth = atoi(m) == 8 ? 8 : 4;
+        if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
+        if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
+        if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
+        return e;
+    }();
+    return env;
+}
+
+// geometry of the exact fp32 sweep (k_scan_small) for this index and k
+struct SweepGeom {
+    int nq_sweep;   // queries per sweep that fit the kernel's LDS budget (1..16)
+    int G;          // blocks
+    int64_t gpb;    // row groups (of 4) per block
+};
+
+template <int NQ, int TT, int METRIC, bool FIX>
+int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, const SweepGeom& sg,
+                        hipStream_t st, const int* flag_list, const int* nflag, float* fix_s, uint32_t* fix_i,
+                        int* fix_lock) {
     const int T = ix->dpad / 64;
-    const size_t lds = (size_t)NQ * ix->dpad * 4 + (size_t)NQ * k * 8 + NQ * 4;
-    auto kern = k_scan_small<NQ, TT, METRIC>;
-    if (lds > 48 * 1024)
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ProfScope ps("knn_scan_small", st);
-    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, (const float4*)ix->xb, qpad, ix->ntotal, T, k,
-                       groups_per_block, gthr, ix->part_s, ix->part_i, nq_real, ix->cur_mask);
+    const size_t lds = (size_t)NQ * ix->dpad * 4 + (size_t)NQ * k * 8 + NQ * 8 + (FIX ? (size_t)4 * k * 8 : 0);
+    auto kern = k_scan_small<NQ, TT, METRIC, FIX>;
+    int rc;
+    if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    ProfScope ps(FIX ? "knn_fix_scan" : "knn_scan_small", st);
+    hipLaunchKernelGGL(kern, dim3(sg.G), dim3(256), lds, st, (const float4*)ix->xb, qpad, ix->ntotal, T, k, sg.gpb, gthr,
+                       ix->part_s, ix->part_i, nq_real, ix->cur_mask, flag_list, nflag, fix_s, fix_i, fix_lock);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
 
-template <int NQ>
-int launch_scan_small_nq(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, int G,
-                         int64_t gpb, hipStream_t st) {
+template <int NQ, bool FIX>
+int launch_scan_small_nq(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, const SweepGeom& sg,
+                         hipStream_t st, const int* flag_list = nullptr, const int* nflag = nullptr,
+                         float* fix_s = nullptr, uint32_t* fix_i = nullptr, int* fix_lock = nullptr) {
     const bool ip = ix->metric == CSS_METRIC_IP;
     if (ix->dpad == 768) {
-        return ip ? launch_scan_small_t<NQ, 12, CSS_METRIC_IP>(ix, qpad, nq_real, k, gthr, G, gpb, st)
-                  : launch_scan_small_t<NQ, 12, CSS_METRIC_L2>(ix, qpad, nq_real, k, gthr, G, gpb, st);
+        return ip ? launch_scan_small_t<NQ, 12, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock)
+                  : launch_scan_small_t<NQ, 12, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
     }
-    return ip ? launch_scan_small_t<NQ, 0, CSS_METRIC_IP>(ix, qpad, nq_real, k, gthr, G, gpb, st)
-              : launch_scan_small_t<NQ, 0, CSS_METRIC_L2>(ix, qpad, nq_real, k, gthr, G, gpb, st);
+    return ip ? launch_scan_small_t<NQ, 0, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock)
+              : launch_scan_small_t<NQ, 0, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
 }
 
 int grow_part(css_index* ix, size_t entries) {
@@ -1136,92 +1293,109 @@ inline int host_f2key(float f) {
 }
 
 // Queries [q0, q0+nqc) (nqc <= 16) against the whole index, results to D/I rows q0...
-int search_chunk_small(css_index* ix, int q0, int nqc, int k, int G, int64_t gpb, float* D_dev, int64_t* I_dev,
+int search_chunk_small(css_index* ix, int q0, int nqc, int k, const SweepGeom& sg, float* D_dev, int64_t* I_dev,
                        hipStream_t st) {
     int* gthr = ix->gthr + q0;
     hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(64), 0, st, gthr, nqc, host_f2key(-INFINITY));
     CSS_LAUNCH_CHECK();
     const float* qp = ix->qpad + (size_t)q0 * ix->dpad;
     int rc;
-    if (nqc <= 1) rc = launch_scan_small_nq<1>(ix, qp, nqc, k, gthr, G, gpb, st);
-    else if (nqc <= 2) rc = launch_scan_small_nq<2>(ix, qp, nqc, k, gthr, G, gpb, st);
+    if (nqc <= 1) rc = launch_scan_small_nq<1, false>(ix, qp, nqc, k, gthr, sg, st);
+    else if (nqc <= 2) rc = launch_scan_small_nq<2, false>(ix, qp, nqc, k, gthr, sg, st);
     else if (nqc <= 8)  // (an NQ=4 instantiation spills under hipcc 7.2; 3..8 share NQ=8)
-         rc = launch_scan_small_nq<8>(ix, qp, nqc, k, gthr, G, gpb, st);
-    else rc = launch_scan_small_nq<16>(ix, qp, nqc, k, gthr, G, gpb, st);
+         rc = launch_scan_small_nq<8, false>(ix, qp, nqc, k, gthr, sg, st);
+    else rc = launch_scan_small_nq<16, false>(ix, qp, nqc, k, gthr, sg, st);
     if (rc != CSS_OK) return rc;
     {
         ProfScope ps("knn_merge", st);
         if (ix->metric == CSS_METRIC_IP)
-            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_IP>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, G,
+            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_IP>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, sg.G,
                                k, gthr, ix->qnorm2 + q0, ix->id_base, D_dev + (size_t)q0 * k,
-                               I_dev + (size_t)q0 * k, 0);
+                               I_dev + (size_t)q0 * k, 0, (float*)nullptr, (uint32_t*)nullptr, (int*)nullptr);
         else
-            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_L2>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, G,
+            hipLaunchKernelGGL(k_merge_final<CSS_METRIC_L2>, dim3(nqc), dim3(256), 0, st, ix->part_s, ix->part_i, sg.G,
                                k, gthr, ix->qnorm2 + q0, ix->id_base, D_dev + (size_t)q0 * k,
-                               I_dev + (size_t)q0 * k, 0);
+                               I_dev + (size_t)q0 * k, 0, (float*)nullptr, (uint32_t*)nullptr, (int*)nullptr);
         CSS_LAUNCH_CHECK();
     }
     return CSS_OK;
 }
 
+// Device-side exact fix-up of the queries a candidate path flagged (overflowing buffer or band, band not closed):
+// two launches that return at once when nothing is flagged.  All pointers are already offset to the chunk's
+// first query; the flagging kernel has reset gthr / fix lists / locks of every flagged query.
+int launch_fixup(css_index* ix, const float* qpad, int nq, int k, int* gthr, const int* flag_list, const int* nflag,
+                 float* fix_s, uint32_t* fix_i, int* fix_lock, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
+                 hipStream_t st) {
+    int rc;
+    if (sg.nq_sweep >= 8) rc = launch_scan_small_nq<8, true>(ix, qpad, 8, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
+    else if (sg.nq_sweep >= 2) rc = launch_scan_small_nq<2, true>(ix, qpad, 2, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
+    else rc = launch_scan_small_nq<1, true>(ix, qpad, 1, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
+    if (rc != CSS_OK) return rc;
+    const int grid = std::max(1, std::min(nq, 64));
+    if (ix->metric == CSS_METRIC_IP)
+        hipLaunchKernelGGL(k_fix_write<CSS_METRIC_IP>, dim3(grid), dim3(64), 0, st, flag_list, nflag, fix_s, fix_i, k,
+                           ix->id_base, D_dev, I_dev);
+    else
+        hipLaunchKernelGGL(k_fix_write<CSS_METRIC_L2>, dim3(grid), dim3(64), 0, st, flag_list, nflag, fix_s, fix_i, k,
+                           ix->id_base, D_dev, I_dev);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
 
-// Query batches: coarse bf16 scan + exact rescoring (default when the index keeps bf16 shadow rows),
-// split-bf16 MFMA (CSS_KNN_BATCH=split, and the fallback) or exact fp32 MFMA (CSS_KNN_BATCH=fp32, verification).
-int g_knn_batch_split = -1;
-int g_knn_batch_coarse = -1;
-int g_knn_dbg = -1;  // CSS_KNN_DBG: timing experiments on k_scan_coarse (results are wrong when set)
-
-template <int METRIC>
-int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
-    if (g_knn_batch_split < 0) {
-        const char* m = getenv("CSS_KNN_BATCH");
-        g_knn_batch_split = (m && std::string(m) == "fp32") ? 0 : 1;
+// workspaces shared by the candidate paths: thresholds, candidate buffers, flags, fix-up lists for nq_pad queries
+int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
+    int rc;
+    if ((rc = grow(&ix->cthr, &ix->cthr_cap, nq_pad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, nq_pad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 1)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->fix_lock, &ix->fix_lock_cap, nq_pad)) != CSS_OK) return rc;
+    const size_t need = nq_pad * (size_t)k;
+    if (need > ix->fix_cap) {
+        if (ix->fix_s) CSS_HIP_TRY(hipFree(ix->fix_s));
+        if (ix->fix_i) CSS_HIP_TRY(hipFree(ix->fix_i));
+        ix->fix_s = nullptr;
+        ix->fix_i = nullptr;
+        ix->fix_cap = 0;
+        CSS_HIP_TRY(hipMalloc((void**)&ix->fix_s, need * sizeof(float)));
+        CSS_HIP_TRY(hipMalloc((void**)&ix->fix_i, need * sizeof(uint32_t)));
+        ix->fix_cap = need;
     }
-    const bool split = g_knn_batch_split != 0;
-    const bool big = split && nq > 128 && k <= 14;  // 256x256 tiles (8 waves) for real batches
-    const int BMs = big ? 256 : MF_BM, BNs = big ? 256 : MF_BN;
-    const int nq_pad = (nq + BNs - 1) / BNs * BNs;  // <= nq + 255 (qpad / gthr have 256 rows of slack)
-    const int nqtiles = nq_pad / BNs;
-    const int64_t ntiles = (ix->ntotal + BMs - 1) / BMs;
-    // fp32 kernel: staging + per-wave scratch + lists; split kernels: staging + lists (the slow-path
-    // scratch borrows a staging buffer).  <= 80 KiB means two blocks share a CU.
-    const size_t lds = split ? (size_t)(2 * BMs * MF_BK + 2 * BNs * MF_BK + BMs + 4) * 4 + (size_t)BNs * k * 8
-                             : (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 +
-                                   (size_t)MF_BN * k * 8;
-    const int bpc = (split && !big && lds <= 80 * 1024) ? 2 : 1;
+    return CSS_OK;
+}
+
+// largest k the MFMA kernels' LDS lists hold next to their staging buffers
+constexpr int kMfmaMaxK = 64;
+// extra ranks the split-operand candidate scan keeps beyond k (the band must close inside them, else the
+// query is flagged and re-run exactly)
+constexpr int kSplitExtra = 4;
+// |split score - x.q| <= kSplitEps ||q|| max||x||: operand residuals 2 x 2^-16, the dropped l.l term 2^-16,
+// 144 fp32 accumulation steps 2^-16.8 -- together < 3.6 x 2^-16; 2^-14 leaves a margin
+constexpr float kSplitEps = 6.103515625e-05f;
+
+// Exact fp32 batched scan (CSS_SEARCH_EXACT_FP32 with more than 16 queries, CSS_KNN_BATCH=fp32):
+// v_mfma_f32_32x32x2_f32, bit-exact fmaf chains, scores written as they are.
+template <int METRIC>
+int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
+    const int nq_pad = (nq + MF_BN - 1) / MF_BN * MF_BN;  // <= nq + 127 (qpad / gthr have 256 rows of slack)
+    const int nqtiles = nq_pad / MF_BN;
+    const int64_t ntiles = (ix->ntotal + MF_BM - 1) / MF_BM;
+    const size_t lds = (size_t)(2 * MF_BM * MF_BK + 2 * MF_BN * MF_BK + 4 * 32 * 33 + MF_BM) * 4 + (size_t)MF_BN * k * 8;
     // strips in multiples of 8 for the XCD-aware block decode
-    int nstrips = std::max(8, bpc * ix->num_cus / nqtiles / 8 * 8);
+    int nstrips = std::max(8, ix->num_cus / nqtiles / 8 * 8);
     nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
     const int64_t tps = (ntiles + nstrips - 1) / nstrips;
     int rc;
     if ((rc = grow_part(ix, (size_t)nq * nstrips * k)) != CSS_OK) return rc;
     if (nq_pad > nq)
         CSS_HIP_TRY(hipMemsetAsync(ix->qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
-    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad,
-                       host_f2key(-INFINITY));
+    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad, host_f2key(-INFINITY));
     CSS_LAUNCH_CHECK();
-    if (split) {
-        if ((rc = grow(&ix->qsplit, &ix->qsplit_cap, (size_t)nq_pad * ix->dpad * 2)) != CSS_OK) return rc;
-        const int64_t ne = (int64_t)nq_pad * ix->dpad;
-        hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ix->qpad, ix->qsplit,
-                           (int64_t)nq_pad, ix->dpad);
-        CSS_LAUNCH_CHECK();
-        ProfScope ps("knn_scan_mfma", st);
-        if (big) {
-            auto kern = k_scan_mfma_split<METRIC, 8, 8>;
-            CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(512), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
-        } else {
-            auto kern = k_scan_mfma_split<METRIC, 4, 4>;
-            CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
-        }
-        CSS_LAUNCH_CHECK();
-    } else {
-        auto kern = k_scan_mfma<METRIC>;
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = k_scan_mfma<METRIC>;
+    if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    {
         ProfScope ps("knn_scan_mfma", st);
         hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qpad, nq,
                            ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
@@ -1230,21 +1404,88 @@ int launch_scan_mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev,
     {
         ProfScope ps("knn_merge", st);
         hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, k,
-                           ix->gthr, ix->qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0);
+                           ix->gthr, ix->qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0,
+                           (float*)nullptr, (uint32_t*)nullptr, (int*)nullptr);
         CSS_LAUNCH_CHECK();
     }
     return CSS_OK;
 }
 
-// Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [0, nq) of ix->qpad; nq <= 4096.
-// Returns the number of flagged queries (their ids in `flagged`) whose result must be recomputed on the exact path.
+// Batched candidate path of an index WITHOUT bf16 shadow rows (shards beyond ~38 M rows of 768 floats, or
+// css_index_set_shadow(0)): the coarse scores are split-operand products formed from the fp32 rows
+// (k_scan_mfma_split: h.h + h.l + l.h, error <= kSplitEps ||q|| max||x||), the scan keeps k + kSplitExtra
+// ranks per query, and k_coarse_select<FINAL> rescores the band in fp32 exactly as the bf16 cascade does.  A
+// query whose band does not close inside the kept ranks is flagged and re-run by the device-side fix-up.
+template <int METRIC>
+int launch_scan_split_rescore(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
+                              hipStream_t st) {
+    const int kp = k + kSplitExtra;
+    const bool big = nq > 128 && kp <= 14;  // 256x256 tiles (8 waves) for real batches
+    const int BMs = big ? 256 : MF_BM, BNs = big ? 256 : MF_BN;
+    const int nq_pad = (nq + BNs - 1) / BNs * BNs;  // <= nq + 255 (qpad / gthr have 256 rows of slack)
+    const int nqtiles = nq_pad / BNs;
+    const int64_t ntiles = (ix->ntotal + BMs - 1) / BMs;
+    // staging + lists (the slow-path scratch borrows a staging buffer); <= 80 KiB means two blocks share a CU
+    const size_t lds = (size_t)(2 * BMs * MF_BK + 2 * BNs * MF_BK + BMs + 4) * 4 + (size_t)BNs * kp * 8;
+    const int bpc = (!big && lds <= 80 * 1024) ? 2 : 1;
+    int nstrips = std::max(8, bpc * ix->num_cus / nqtiles / 8 * 8);
+    nstrips = (int)std::min<int64_t>(nstrips, (ntiles + 7) / 8 * 8);
+    const int64_t tps = (ntiles + nstrips - 1) / nstrips;
+    int rc;
+    if ((rc = grow_part(ix, (size_t)nq * nstrips * kp)) != CSS_OK) return rc;
+    if ((rc = grow_candidate_ws(ix, (size_t)nq_pad, k)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->qsplit, &ix->qsplit_cap, (size_t)nq_pad * ix->dpad * 2)) != CSS_OK) return rc;
+    int* flags = ix->cflags;
+    int* flag_list = ix->cflags + nq_pad;
+    int* nflag = ix->cflags + 2 * nq_pad;
+    if (nq_pad > nq)
+        CSS_HIP_TRY(hipMemsetAsync(ix->qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
+    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad, host_f2key(-INFINITY));
+    hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags, nflag,
+                       nq, nq_pad, 0);
+    const int64_t ne = (int64_t)nq_pad * ix->dpad;
+    hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ix->qpad, ix->qsplit,
+                       (int64_t)nq_pad, ix->dpad);
+    CSS_LAUNCH_CHECK();
+    ProfScope all("knn_split_cascade", st);
+    {
+        ProfScope ps("knn_scan_split", st);
+        if (big) {
+            auto kern = k_scan_mfma_split<METRIC, 8, 8>;
+            if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(512), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
+                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
+        } else {
+            auto kern = k_scan_mfma_split<METRIC, 4, 4>;
+            if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
+                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
+        }
+        CSS_LAUNCH_CHECK();
+    }
+    // the kp best split scores of every query -> its candidate buffer (scores stay in the scan's form: IP dot
+    // products, L2 2 x.q - ||x||^2, the form k_coarse_select expects of coarse scores)
+    hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, ix->gthr,
+                       ix->qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
+                       ix->cand_n);
+    hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
+                       flags, nflag, flag_list, ix->qnorm2, ix->maxn2, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, k,
+                       ix->qpad, ix->xb, ix->dpad, ix->id_base, D_dev, I_dev, kp, ix->gthr, ix->fix_s, ix->fix_i,
+                       ix->fix_lock);
+    CSS_LAUNCH_CHECK();
+    return launch_fixup(ix, ix->qpad, nq, k, ix->gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
+                        sg, st);
+}
+
+// Coarse bf16 scan + exact rescoring (css_knn_coarse.h) for queries [q0, q0 + nq) of ix->qpad; nq <= 4096.
 template <int NQ, int TT, bool MAIN>
 int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
                           hipStream_t st) {
     const size_t lds = (size_t)NQ * ix->dpad * sizeof(float);
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
     auto kern = k_sweep_coarse<NQ, TT, MAIN>;
-    if (lds > 48 * 1024) CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int rc;
+    if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->xh, qpad, ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
                        ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, ix->cur_mask,
                        ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr);
@@ -1262,9 +1503,16 @@ int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t cou
     return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
 }
 
+// grid of the persistent k_scan_coarse launches and the largest query chunk it can serve: the nqt blocks
+// that share a row tile must fit the grid / 8 blocks of one XCD group (a CPX partition has few CUs)
+inline int coarse_grid(const css_index* ix) { return std::max(8, ix->num_cus / 8 * 8); }
+inline int coarse_max_chunk(const css_index* ix) { return std::min(4096, coarse_grid(ix) / 8 * CZ_T); }
+
 // sweep = true: 1..4 queries through the HBM-bound bf16 sweep (k_sweep_coarse) instead of the MFMA scan.
+// Everything is enqueued on `st`; nothing waits for the device (flagged queries are fixed up on the device).
 int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st,
-                       std::vector<int>* flagged, bool sweep) {
+                       const SweepGeom& sg, bool sweep) {
+    const KnnEnv& env = knn_env();
     const float* qpad = ix->qpad + (size_t)q0 * ix->dpad;
     const float* qnorm2 = ix->qnorm2 + q0;
     D_dev += (size_t)q0 * k;
@@ -1277,11 +1525,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const float* xn2 = l2 ? ix->xnorm2 : nullptr;  // L2: coarse score = 2 x.q - ||x||^2
     int rc;
     if (!sweep && (rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cthr, &ix->cthr_cap, (size_t)nq_pad)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, (size_t)nq_pad)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cflags, &ix->cflags_cap, (size_t)2 * nq_pad + 1)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, (size_t)nq_pad * CZ_CAP)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, (size_t)nq_pad * CZ_CAP)) != CSS_OK) return rc;
+    if ((rc = grow_candidate_ws(ix, (size_t)nq_pad, k)) != CSS_OK) return rc;
     int* flags = ix->cflags;
     int* flag_list = ix->cflags + nq_pad;
     int* nflag = ix->cflags + 2 * nq_pad;
@@ -1293,12 +1537,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // stage is 3/4 of the rows and appends ~3k + band candidates per query.  g = 8 (CSS_KNN_GROWTH=8; stage 0 then
     // holds up to 15 tiles = 3840 rows per query, still inside the 4096-slot buffer) measured 2 % slower for batches
     // (more appends in the main stage) and the same for single queries.
-    static int growth = -1;
-    if (growth < 0) {
-        const char* m = getenv("CSS_KNN_GROWTH");
-        growth = (m && atoi(m) == 8) ? 8 : 4;
-    }
-    const int g = growth;
+    const int g = env.growth;
     while (ntiles / (s0 * g) >= 2) s0 *= g;
     const int64_t n0 = (ntiles + s0 - 1) / s0;
 
@@ -1316,41 +1555,27 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
                             int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int);
-    if (g_knn_dbg < 0) {
-        const char* m = getenv("CSS_KNN_DBG");
-        g_knn_dbg = m ? atoi(m) : 0;
-    }
     // (the DBG instantiations honour CSS_KNN_DBG; the product kernels carry no timing switches)
     // v_mfma_f32_16x16x32_bf16 by default: same cycles per flop and LDS traffic as 32x32x16, but the chip holds a
     // higher clock under it (measured in one session: main stage 11.1 ms vs 12.1 ms); CSS_KNN_MFMA=32 for A/B runs
-    static int mfma_shape = -1;
-    if (mfma_shape < 0) {
-        const char* m = getenv("CSS_KNN_MFMA");
-        mfma_shape = (m && atoi(m) == 32) ? 32 : 16;
-    }
-    const scan_fn f_stage0 = mfma_shape == 16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>;
-    const scan_fn f_mid = g_knn_dbg ? k_scan_coarse<false, false, true>
-                                    : (mfma_shape == 16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
-    const scan_fn f_main = g_knn_dbg ? k_scan_coarse<false, true, true>
-                                     : (mfma_shape == 16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>);
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's code object
-    if (!attr_set[ix->device & 63]) {
+    const bool m16 = env.mfma_shape == 16;
+    const scan_fn f_stage0 = m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>;
+    const scan_fn f_mid = env.dbg ? k_scan_coarse<false, false, true>
+                                  : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
+    const scan_fn f_main = env.dbg ? k_scan_coarse<false, true, true>
+                                   : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>);
+    if (!sweep)
         for (scan_fn f : {f_stage0, f_mid, f_main})
-            CSS_HIP_TRY(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[ix->device & 63] = true;
-    }
-    const int grid = std::max(8, ix->num_cus / 8 * 8);
-    static int pacing = -1;  // CSS_KNN_PACE=0 disables the sibling pacing of k_scan_coarse (A/B experiments)
-    if (pacing < 0) {
-        const char* m = getenv("CSS_KNN_PACE");
-        pacing = (m && m[0] == '0') ? 0 : 1;
-    }
+            if ((rc = css::ensure_dynamic_lds((const void*)f, lds, ix->device)) != CSS_OK) return rc;
+    const int grid = coarse_grid(ix);
+    CSS_REQUIRE(sweep || (grid / 8) / nqt >= 1, "css_index_search: %d query tiles do not fit a grid of %d blocks", nqt, grid);
     constexpr int kPaceGroups = 512, kPaceStages = 20;
-    if (!sweep && pacing) {
+    if (!sweep && env.pacing) {
         if ((rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
         CSS_HIP_TRY(hipMemsetAsync(ix->cpace, 0, sizeof(int) * kPaceGroups * kPaceStages, st));
     }
     int stage_idx = 0;
+    {
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
     for (int64_t s = s0;; s /= g) {
         const bool stage0 = s == s0;
@@ -1365,39 +1590,30 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
-            int* pace = (pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
+            int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, xn2, g_knn_dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, xn2, env.dbg);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;
         if (s == 1) {
             hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
                                ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
-                               ix->id_base, D_dev, I_dev);
+                               ix->id_base, D_dev, I_dev, 0, ix->gthr + q0, ix->fix_s, ix->fix_i, ix->fix_lock);
             CSS_LAUNCH_CHECK();
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
                            ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
-                           ix->id_base, D_dev, I_dev);
+                           ix->id_base, D_dev, I_dev, 0, ix->gthr + q0, ix->fix_s, ix->fix_i, ix->fix_lock);
         CSS_LAUNCH_CHECK();
     }
-    // one host round trip per batch: which queries overflowed their candidate buffer or band?
-    int h_nflag = 0;
-    CSS_HIP_TRY(hipMemcpyAsync(&h_nflag, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
-    CSS_HIP_TRY(hipStreamSynchronize(st));
-    if (h_nflag > 0) {
-        std::vector<int> f((size_t)h_nflag);
-        CSS_HIP_TRY(hipMemcpyAsync(f.data(), flag_list, (size_t)h_nflag * sizeof(int), hipMemcpyDeviceToHost, st));
-        CSS_HIP_TRY(hipStreamSynchronize(st));
-        for (int v : f) flagged->push_back(q0 + v);
     }
-    return CSS_OK;
+    // queries whose candidate buffer or band overflowed (thousands of duplicate rows, a zero query): exact
+    // fp32 sweep on the device, two launches that return at once when the flag count is zero
+    return launch_fixup(ix, qpad, nq, k, ix->gthr + q0, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
+                        sg, st);
 }
-
-// largest k the MFMA kernel's LDS lists hold next to its staging buffers
-constexpr int kMfmaMaxK = 64;
 
 // q_dev: raw [nq, dim] device queries.  Caller holds ws_mu and a shared lock on mu.
 int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
@@ -1405,7 +1621,10 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     CSS_REQUIRE(k >= 1 && k <= CSS_MAX_K, "css_index_search: k=%d outside [1, %d]", k, CSS_MAX_K);
     CSS_REQUIRE(nq >= 0 && nq < (1 << 24), "css_index_search: nq=%lld out of range", (long long)nq);
     if (nq == 0) return CSS_OK;
+    const KnnEnv& env = knn_env();
     int rc;
+    // rows appended on another stream (css_index_add_dev / _add_synthetic) must have landed
+    if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(st, ix->ingest_ev, 0));
     if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 256) * ix->dpad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
@@ -1418,63 +1637,57 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
         CSS_LAUNCH_CHECK();
     }
     if (ix->ntotal == 0) {
-        // nothing to scan: pad (cannot be reached through the reference: src/storage.py:421-422)
-        std::vector<float> hd((size_t)nq * k, ix->metric == CSS_METRIC_IP ? -FLT_MAX : FLT_MAX);
-        std::vector<int64_t> hi((size_t)nq * k, -1);
-        CSS_HIP_TRY(hipMemcpyAsync(D_dev, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, st));
-        CSS_HIP_TRY(hipMemcpyAsync(I_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, st));
-        CSS_HIP_TRY(hipStreamSynchronize(st));
+        const int64_t n = nq * k;
+        hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, D_dev, I_dev, n,
+                           ix->metric == CSS_METRIC_IP ? -FLT_MAX : FLT_MAX);
+        CSS_LAUNCH_CHECK();
         return CSS_OK;
     }
-    // sweep geometry of the small-batch kernel (also the per-query fallback of the coarse path)
-    int nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 4));
-    CSS_REQUIRE(nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
+    // sweep geometry of the small-batch kernel (also the exact fix-up of the candidate paths)
+    SweepGeom sg;
+    sg.nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 8));
+    CSS_REQUIRE(sg.nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
     // enough blocks to fill the chip (8 per CU) but at least ~64 row groups of work each
     const int64_t ngroups = (ix->ntotal + 3) / 4;
     int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ix->num_cus * 8, (ngroups + 63) / 64));
-    const int64_t gpb = (ngroups + G - 1) / G;
-    G = (ngroups + gpb - 1) / gpb;
-    if (g_knn_batch_coarse < 0) {
-        const char* m = getenv("CSS_KNN_BATCH");
-        g_knn_batch_coarse = (m && (std::string(m) == "fp32" || std::string(m) == "split")) ? 0 : 1;
-    }
-    // coarse paths need room for k rows in stage 0 (always true) and the bf16 shadow rows
-    // The cascade costs ~10-16 launches and one host round trip: below these sizes (measured on MI355X, 768-d:
-    // 1 query 0.18 vs 0.13 ms at 10 k rows, crossover ~1.2 M; 8 queries crossover ~0.4 M; 32+ queries always
-    // ahead) the exact fp32 kernels answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
+    sg.gpb = (ngroups + G - 1) / G;
+    sg.G = (int)((ngroups + sg.gpb - 1) / sg.gpb);
+
+    const int mode = ix->search_mode;
+    const bool batch_ok = nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0;  // the MFMA scan kernels apply
+    // The cascade costs ~10-16 launches: below these sizes (measured on MI355X, 768-d: 1 query 0.18 vs 0.13 ms at
+    // 10 k rows, crossover ~1.2 M; 8 queries crossover ~0.4 M; 32+ queries always ahead) the exact fp32 kernels
+    // answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
     const bool coarse_pays = nq > 16 || (nq > 4 ? ix->ntotal >= 400000 : ix->ntotal >= 1200000);
-    if (g_knn_batch_coarse && (ix->search_mode == CSS_SEARCH_COARSE || (coarse_pays && ix->search_mode == CSS_SEARCH_AUTO)) &&
-        ix->xh != nullptr) {
-        std::vector<int> flagged;
-        if (nq <= 4) {  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
-            if ((rc = launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, &flagged, true)) != CSS_OK) return rc;
-        } else {
-            for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
-                const int nqc = (int)std::min<int64_t>(4096, nq - q0);
-                if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, &flagged, false)) != CSS_OK) return rc;
-            }
+    const bool want_candidates = env.batch == 0 && (mode == CSS_SEARCH_COARSE || (mode == CSS_SEARCH_AUTO && coarse_pays));
+    if (want_candidates && ix->xh != nullptr) {
+        if (nq <= 4)  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
+            return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true);
+        const int chunk = coarse_max_chunk(ix);
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+            const int nqc = (int)std::min<int64_t>(chunk, nq - q0);
+            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, sg, false)) != CSS_OK) return rc;
         }
-        if (flagged.empty()) return CSS_OK;
-        // candidate buffer / band overflow (e.g. thousands of duplicate rows): exact path for those queries
-        if (flagged.size() > 32 && nq > 16 && k <= kMfmaMaxK)
-            return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
-                                               : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
-        if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
-        for (int q : flagged)
-            if ((rc = search_chunk_small(ix, q, 1, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;
         return CSS_OK;
     }
-    if (nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0) {
-        return ix->metric == CSS_METRIC_IP ? launch_scan_mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
-                                           : launch_scan_mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
+    // no shadow rows: batches still take a candidate path, with split-operand coarse scores from the fp32 rows
+    if (batch_ok && k + kSplitExtra <= kMfmaMaxK && (env.batch == 1 || (want_candidates && ix->xh == nullptr))) {
+        return ix->metric == CSS_METRIC_IP ? launch_scan_split_rescore<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, sg, st)
+                                           : launch_scan_split_rescore<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, sg, st);
     }
-    if ((rc = grow_part(ix, (size_t)nq_sweep * G * k)) != CSS_OK) return rc;
-    for (int64_t q0 = 0; q0 < nq; q0 += nq_sweep) {
-        const int nqc = (int)std::min<int64_t>(nq_sweep, nq - q0);
-        if ((rc = search_chunk_small(ix, (int)q0, nqc, k, (int)G, gpb, D_dev, I_dev, st)) != CSS_OK) return rc;
+    // exact fp32 arithmetic inside the scan: fp32-input MFMA for batches, VALU sweeps for up to 16 queries
+    if (batch_ok && (mode == CSS_SEARCH_EXACT_FP32 || env.batch == 2)) {
+        return ix->metric == CSS_METRIC_IP ? launch_scan_fp32mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
+                                           : launch_scan_fp32mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
+    }
+    if ((rc = grow_part(ix, (size_t)sg.nq_sweep * sg.G * k)) != CSS_OK) return rc;
+    for (int64_t q0 = 0; q0 < nq; q0 += sg.nq_sweep) {
+        const int nqc = (int)std::min<int64_t>(sg.nq_sweep, nq - q0);
+        if ((rc = search_chunk_small(ix, (int)q0, nqc, k, sg, D_dev, I_dev, st)) != CSS_OK) return rc;
     }
     return CSS_OK;
 }
+
 
 }  // namespace
 
@@ -1499,9 +1712,11 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
         delete ix;
         return css::hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
     }
-    e = hipMalloc((void**)&ix->maxn2, sizeof(int));
+    e = hipEventCreateWithFlags(&ix->ingest_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, sizeof(int));
     if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, sizeof(int));
     if (e != hipSuccess) {
+        if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
         (void)hipStreamDestroy(ix->stream);
         delete ix;
         return css::hip_fail(e, "hipMalloc(maxn2)", __FILE__, __LINE__);
@@ -1514,11 +1729,13 @@ int css_index_free(css_index* ix) {
     if (!ix) return CSS_OK;
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
+    if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws};
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
+    if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
     (void)hipStreamDestroy(ix->stream);
     delete ix;
     return CSS_OK;
@@ -1530,6 +1747,7 @@ int css_index_reset(css_index* ix) {
     ix->ntotal = 0;
     if (!ix->xh) ix->shadow = -1;
     DeviceGuard g(ix->device);
+    if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
     CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, sizeof(int), ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
@@ -1577,6 +1795,25 @@ int css_index_set_search_mode(css_index* ix, int mode) {
     return CSS_OK;
 }
 
+int css_index_set_shadow(css_index* ix, int policy) {
+    CSS_REQUIRE(ix, "css_index_set_shadow: NULL index");
+    CSS_REQUIRE(policy >= -1 && policy <= 1, "css_index_set_shadow: policy %d outside {-1, 0, 1}", policy);
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    if (ix->ntotal != 0) {
+        css::set_error("css_index_set_shadow: the index already holds %lld rows (set the policy on an empty index)",
+                       (long long)ix->ntotal);
+        return CSS_ERR_STATE;
+    }
+    DeviceGuard g(ix->device);
+    ix->shadow_policy = policy;
+    if (ix->xh) {  // start over: the next add decides again
+        CSS_HIP_TRY(hipFree(ix->xh));
+        ix->xh = nullptr;
+    }
+    ix->shadow = -1;
+    return CSS_OK;
+}
+
 int css_index_set_id_base(css_index* ix, int64_t base) {
     CSS_REQUIRE(ix, "css_index_set_id_base: NULL index");
     std::unique_lock<std::shared_mutex> lk(ix->mu);
@@ -1592,6 +1829,7 @@ int css_index_add(css_index* ix, const float* x_host, int64_t n, int normalize) 
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     std::lock_guard<std::mutex> wl(ix->ws_mu);
     DeviceGuard g(ix->device);
+    if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc != CSS_OK) return rc;
     // stage through a bounded device buffer so huge adds do not double the footprint
@@ -1623,6 +1861,9 @@ int css_index_add_dev(css_index* ix, const float* x_dev, int64_t n, int normaliz
             return rc;
         ix->ntotal += m;
     }
+    // the rows are written asynchronously on the caller's stream: later searches / reallocations / exports wait for this
+    CSS_HIP_TRY(hipEventRecord(ix->ingest_ev, (hipStream_t)stream));
+    ix->ingest_pending = true;
     return CSS_OK;
 }
 
@@ -1641,6 +1882,8 @@ int css_index_add_synthetic(css_index* ix, int64_t n, uint64_t seed, int64_t fir
             return rc;
         ix->ntotal += m;
     }
+    CSS_HIP_TRY(hipEventRecord(ix->ingest_ev, (hipStream_t)stream));
+    ix->ingest_pending = true;
     return CSS_OK;
 }
 
@@ -1652,6 +1895,7 @@ int css_index_export(const css_index* cix, int64_t row0, int64_t n, float* x_out
                 (long long)row0, (long long)(row0 + n), (long long)ix->ntotal);
     if (n == 0) return CSS_OK;
     DeviceGuard g(ix->device);
+    if (ix->ingest_pending) CSS_HIP_TRY(hipEventSynchronize(ix->ingest_ev));
     CSS_HIP_TRY(hipMemcpy2D(x_out_host, (size_t)ix->dim * 4, ix->xb + (size_t)row0 * ix->dpad, (size_t)ix->dpad * 4,
                             (size_t)ix->dim * 4, (size_t)n, hipMemcpyDeviceToHost));
     return CSS_OK;

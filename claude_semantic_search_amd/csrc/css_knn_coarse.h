@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                                                        const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
                                                        const float* __restrict__ qpad, const float* __restrict__ xb,
                                                        int dpad, int64_t id_base, float* __restrict__ D,
-                                                       int64_t* __restrict__ I) {
+                                                       int64_t* __restrict__ I, int closed_n, int* __restrict__ gthr,
+                                                       float* __restrict__ fix_s, uint32_t* __restrict__ fix_i,
+                                                       int* __restrict__ fix_lock) {
     __shared__ float s[CZ_CAP];
     __shared__ uint32_t id[CZ_CAP];
     __shared__ int cnt;
@@ -576,8 +578,22 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
             if (overflow) flags[q] = 1;
         }
     } else {
-        const bool bad = overflow || flags[q] != 0 || m > CZ_RMAX;
-        if (bad && tid == 0) flag_list[atomicAdd(nflag, 1)] = q;
+        // closed_n > 0 (split-operand scan, which keeps only its closed_n best scores): a band that reaches the
+        // last kept rank may continue beyond it
+        const bool bad = overflow || flags[q] != 0 || m > CZ_RMAX || (closed_n > 0 && m >= closed_n);
+        if (bad) {
+            // flagged: the exact fix-up (k_scan_small<FIX>) recomputes this query; start its global list, threshold
+            // and lock from scratch
+            for (int i = tid; i < k; i += 256) {
+                fix_s[(size_t)q * k + i] = -INFINITY;
+                fix_i[(size_t)q * k + i] = kInvalidRow;
+            }
+            if (tid == 0) {
+                gthr[q] = f2key(-INFINITY);
+                fix_lock[q] = 0;
+                flag_list[atomicAdd(nflag, 1)] = q;
+            }
+        }
         const int R = min(m, CZ_RMAX);
         __syncthreads();
         // exact fp32 scores of the band rows: one wave per row, fixed summation order

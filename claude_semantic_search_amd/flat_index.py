@@ -143,6 +143,12 @@ class IndexFlat:
             raise ValueError(f"unknown search mode {mode!r}")
         nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))
 
+    def set_shadow(self, policy: Optional[bool]) -> None:
+        """bf16 shadow rows (operand of the candidate scans, +50 % HBM): ``None`` = keep them while they
+        fit (default), ``False`` = never, ``True`` = always.  Only on an empty index; results do not change."""
+        p = -1 if policy is None else (1 if policy else 0)
+        nat.check(nat.lib().css_index_set_shadow(self._handle(), p))
+
     def set_id_base(self, base: int) -> None:
         nat.check(nat.lib().css_index_set_id_base(self._handle(), int(base)))
 

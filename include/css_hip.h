@@ -81,6 +81,10 @@ int css_index_ntotal(const css_index* ix, int64_t* n);
 int css_index_dim(const css_index* ix, int* dim);
 int css_index_metric(const css_index* ix, int* metric);
 int css_index_device(const css_index* ix, int* device);
+/* bf16 shadow rows (the operand of the candidate scans; +50 % HBM next to the fp32 rows): -1 = keep them
+ * while fp32 + bf16 rows fit in 80 % of the HBM (default), 0 = never, 1 = always.  Only on an empty index.
+ * Results do not depend on it: without shadow rows batches form their candidate scores from the fp32 rows. */
+int css_index_set_shadow(css_index* ix, int policy);
 /* Global id of local row 0 (shards of a row-partitioned index). */
 int css_index_set_id_base(css_index* ix, int64_t base);
 
@@ -102,13 +106,16 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * Indexes keep a bf16 shadow copy of the rows while it fits in HBM; searches
  * of large indexes then select candidates with a bf16 scan inside a rigorous
  * error band and return exact fp32 scores of the rescored candidates (same
- * results as the fp32 kernels).  The _dev form enqueues on `stream`; on that
- * candidate path it also waits for the stream once per call (overflow check). */
-/* Search path: CSS_SEARCH_AUTO (default) selects candidates with the bf16 scan and
- * rescores them in fp32 when the index keeps shadow rows and is large enough for the
- * multi-launch cascade to pay (one query: >= 1.2 M rows); CSS_SEARCH_EXACT_FP32 forms
- * every score in fp32 inside the scan kernels (the parity mode of the tests; also what
- * small indexes and indexes without shadow rows use). */
+ * results as the fp32 kernels).  The _dev form only enqueues on `stream` and never
+ * waits for the device: queries whose candidate band overflows are re-run exactly by
+ * two launches that follow every cascade and return at once when there are none.
+ * Rows appended by css_index_add_dev / css_index_add_synthetic on another stream are
+ * ordered before the search by an event (no caller-side synchronisation needed). */
+/* Search path: CSS_SEARCH_AUTO (default) selects candidates with a reduced-precision scan
+ * inside a rigorous error band and rescores them in fp32 where the multi-launch cascade
+ * pays (one query: >= 1.2 M rows; batches always); CSS_SEARCH_EXACT_FP32 forms every score
+ * with fp32 fmaf chains inside the scan kernels (VALU sweeps up to 16 queries, fp32-input
+ * MFMA beyond; the parity mode of the tests, and what small indexes use for few queries). */
 #define CSS_SEARCH_AUTO 0
 #define CSS_SEARCH_EXACT_FP32 1
 #define CSS_SEARCH_COARSE 2 /* the candidate path whatever the index size (AUTO uses it only where it pays) */

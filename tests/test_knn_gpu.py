@@ -426,3 +426,118 @@ def test_invalid_arguments_raise():
         ix.search(np.zeros((1, 8), np.float32), 129)
     D, I = ix.search(np.zeros((1, 8), np.float32), 3)  # empty index: padded
     assert I[0].tolist() == [-1, -1, -1]
+
+
+# ---- device-side exact fix-up of flagged queries (no host round trip on the candidate path) ----------
+@pytest.mark.parametrize("metric", [0, 1])
+def test_many_flagged_queries_are_fixed_up_on_the_device(metric):
+    # 40 queries next to a flood of 5000 identical rows: every one of them overflows its band, so the fix-up
+    # walks several chunks of flagged queries and many blocks merge into each query's global list
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    base = synth.rows(4000, 768, 71)
+    x = np.concatenate([base[:2000], np.repeat(base[11:12], 5000, axis=0), base[2000:]], axis=0)
+    q = np.concatenate([base[11:12] + 0.01 * synth.rows(40, 768, 72), synth.rows(25, 768, 73)], axis=0)
+    norm = metric == 0
+    ix = IndexFlat(768, metric)
+    ix.add(x, normalize=norm)
+    ix.set_search_mode("coarse")
+    ref = ko.FlatIndexOracle(768, metric)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if norm else (x, q)
+    ref.add(xr)
+    for nq in (65, 3):          # MFMA cascade and the few-query sweep cascade
+        nat.prof_reset()
+        nat.prof_enable(True)
+        D, I = ix.search(q[:nq], 10, normalize=norm)
+        nat.prof_enable(False)
+        assert nat.prof_read("knn_fix_scan")[1] >= 1 and nat.prof_read("knn_scan_small")[1] == 0
+        Dr, Ir = ref.search(qr[:nq], 10)
+        D64 = ref.rescore64(qr[:nq], Ir)
+        assert_topk_matches(D, I, Dr, Ir, D64, f"flood metric={metric} nq={nq}")
+        # exact ties inside the flood: the lowest ids win (rows 2000.. are the copies; row 11 is the original)
+        assert I[0].tolist() == [11] + list(range(2000, 2009))
+    nat.prof_reset()
+    ix.close()
+
+
+# ---- indexes without bf16 shadow rows: candidate scores from the fp32 rows (split operands) + fp32 rescoring ----
+@pytest.mark.parametrize("n,nq,k,metric", [(20000, 300, 10, 0), (20000, 300, 10, 1), (9000, 40, 60, 0),
+                                           (3000, 129, 1, 0), (50000, 17, 10, 0)])
+def test_no_shadow_batches_match_oracle(n, nq, k, metric):
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    norm = metric == 0
+    x = synth.rows(n, 768, 100 + n % 97)
+    q = synth.rows(nq, 768, 200 + nq)
+    ix = IndexFlat(768, metric)
+    ix.set_shadow(False)
+    ix.add(x, normalize=norm)
+    ref = ko.FlatIndexOracle(768, metric)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if norm else (x, q)
+    ref.add(xr)
+    Dr, Ir = ref.search(qr, k)
+    D64 = ref.rescore64(qr, Ir)
+    for mode, scope in (("auto", "knn_split_cascade"), ("coarse", "knn_split_cascade"), ("exact_fp32", "knn_scan_mfma")):
+        ix.set_search_mode(mode)
+        nat.prof_reset()
+        nat.prof_enable(True)
+        D, I = ix.search(q, k, normalize=norm)
+        nat.prof_enable(False)
+        assert nat.prof_read(scope)[1] == 1, f"[{mode}] expected the {scope} path"
+        assert nat.prof_read("knn_coarse_cascade")[1] == 0
+        assert_topk_matches(D, I, Dr, Ir, D64, f"no shadow [{mode}] n={n} nq={nq} k={k} metric={metric}")
+    nat.prof_reset()
+    with pytest.raises(RuntimeError):
+        ix.set_shadow(True)      # only on an empty index
+    ix.close()
+
+
+def test_no_shadow_band_beyond_the_kept_ranks_is_fixed_up():
+    # 30 exact copies of the best row: the k + 4 ranks the split scan keeps all tie, the band cannot be shown
+    # closed, the query is flagged and the exact fix-up returns the lowest ids
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    base = synth.rows(6000, 768, 75)
+    x = np.concatenate([base[:3000], np.repeat(base[5:6], 30, axis=0), base[3000:]], axis=0)
+    q = np.concatenate([base[5:6], synth.rows(39, 768, 76)], axis=0)
+    ix = IndexFlatIP(768)
+    ix.set_shadow(False)
+    ix.add(x, normalize=True)
+    nat.prof_reset()
+    nat.prof_enable(True)
+    D, I = ix.search(q, 10, normalize=True)
+    nat.prof_enable(False)
+    assert nat.prof_read("knn_split_cascade")[1] == 1 and nat.prof_read("knn_fix_scan")[1] == 1
+    assert I[0].tolist() == [5] + list(range(3000, 3009)) and np.all(np.abs(D[0] - 1.0) < 1e-6)
+    nat.prof_reset()
+    _ = _check_against_oracle  # (ordinary queries of the same batch are covered by the parametrised test above)
+    ix.close()
+
+
+def test_search_right_behind_an_asynchronous_ingest_on_another_stream():
+    # css_index_add_synthetic only enqueues on the caller's stream; a search on a different stream must still
+    # see the rows, norms and max-norm scalar (ordered by an event inside the library)
+    import torch
+
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    side = torch.cuda.Stream()
+    n = 3_000_000
+    ix = IndexFlatIP(768)
+    ix.reserve(n)
+    ix.add_synthetic(n, seed=44, first_row=0, normalize=True, stream=side.cuda_stream)   # ~6 ms of device work
+    q = synth.rows(40, 768, 45)
+    D, I = ix.search(q, 10, normalize=True)              # host API: runs on the index's own stream
+    torch.cuda.synchronize()
+    D2, I2 = ix.search(q, 10, normalize=True)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    rows = synth.rows(3, 768, 44, first_row=n - 3)
+    rows /= (np.linalg.norm(rows, axis=1, keepdims=True) + 1e-8)
+    d1, i1 = ix.search(rows, 1)
+    assert i1[:, 0].tolist() == [n - 3, n - 2, n - 1] and np.all(np.abs(d1 - 1.0) < 1e-5)
+    ix.close()

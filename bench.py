@@ -5,26 +5,28 @@ Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched b
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``,
 one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[3], the configuration the north-star roofline
-target is quoted on): a 10M x 768 fp32 flat inner-product index resident in HBM,
-a batch of 1000 queries, exact top-10.  A "step" is one pass of the search path
-over the whole query batch.  With N GPUs the SAME 10M-row index is
-row-partitioned over the ranks (strong scaling); each step ends with one RCCL
-all-gather of the per-shard top-k and a merge.
+Workload.  N = 1: BASELINE.json configs[3] (the configuration the north-star roofline target is quoted on): a
+10M x 768 fp32 flat inner-product index resident in HBM, a batch of 1000 queries, exact top-10.  N > 1:
+BASELINE.json configs[4] -- 10 M rows PER GPU (N = 8: the 80M x 768 index), one virtual synthetic index
+row-partitioned over the ranks, the same 1000 queries on every rank: weak scaling.  A "step" is one pass of the
+search path over the whole query batch through the product class (``ShardedFlatIndex.search_tensors``): local
+cascade on every shard -> ONE RCCL all-gather of the packed per-shard top-k (nq*k*12 bytes per rank) -> merge.
+``config.strong_10M`` carries the strong-scaling line of the fixed 10 M-row index for the same N.
 
 The JSON line also carries:
   roofline      dominant kernel of the timed region -- the main stage of the search cascade,
                 k_scan_coarse<false,true,..> (bf16 MFMA bound) -- measured with HIP events on the
                 launch stream inside this run (css_prof_*); `traffic` = HBM-side bytes per launch
                 from the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes).
-  cpu_baseline  the CPU oracle (kind "port") timed on this box's host cores on a
-                bounded sample of the same workload, rank 0 / N=1 only.
-  extra         nq1_k10 / nq1_k100: single-query search (the reference's real call shape) with the
-                HBM roofline of its main sweep stage; masked_half_rows: the same searches with an
-                allow-bitmap; exact_fp32_mode: the parity mode (every score formed in fp32 by the
-                scan kernels) on the same index; encode: batch-256 x 384 encoder forward with its
-                MFMA roofline, per-kernel times, length-mix and text-path (strings in) runs, CPU
-                baseline and parity against the oracle.
+                Sub-objects (same fields): `nq1_k10` -- the single-query search, the reference's real call
+                shape, with the HBM roofline of its main sweep (the north-star's 60 % target); `exact_fp32_mode`
+                -- every score formed by fp32 fmaf chains; `encode` -- batch-256 x 384 encoder forward
+                (BASELINE configs[2]) with chunks/s and its bf16-MFMA roofline (the 40 % target).
+  cpu_baseline  the CPU oracle (kind "port") timed on this box's host cores on a bounded sample of the same
+                workload, rank 0 / N=1 only: blocked SGEMM + heap on all cores; `encode`: the torch oracle at
+                batch 16.
+  extra         details: k'=100 single query, masked search, per-kernel encoder times, length-mix and
+                text-path (strings in) runs, flagged fraction on clustered rows.
 """
 from __future__ import annotations
 
@@ -62,11 +64,14 @@ def parse_args():
     ap.add_argument("--enc-steps", type=int, default=5)
     ap.add_argument("--no-encoder", action="store_true")
     ap.add_argument("--only-encoder", action="store_true", help="development aid: run just the encoder leg")
+    ap.add_argument("--enc-fixed-only", action="store_true", help="encoder leg: only the fixed batch x len shape (counter passes)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling line of the 10 M-row index")
     return ap.parse_args()
 
 
 def cpu_baseline_knn(args, log):
-    """Oracle (numpy/BLAS port of faiss-cpu's batched path) on a bounded row sample."""
+    """faiss-cpu's batched path restated (oracle.knn_oracle.search_blas): blocked SGEMM on every host core (the BLAS
+    numpy links) + a per-query heap fold in C/OpenMP, on a bounded row sample; time scaled to the full index."""
     import numpy as np
     from oracle import knn_oracle as ko
 
@@ -75,27 +80,31 @@ def cpu_baseline_knn(args, log):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
+    ko.set_threads(min(os.cpu_count() or 1, 64))
     q = ko.normalize_rows(ko.synth_rows(args.nq, args.dim, 5))
-    probe_rows = 50_000
+    probe_rows = 100_000
     x = ko.normalize_rows(ko.synth_rows(probe_rows, args.dim, 4))
+    ko.search_blas(x[:20000], q, args.k)     # warm the BLAS threads
     t0 = time.perf_counter()
     ko.search_blas(x, q, args.k)
     t_probe = time.perf_counter() - t0
-    rows = int(min(2_000_000, max(probe_rows, probe_rows * args.cpu_seconds / max(t_probe, 1e-3))))
+    rows = int(min(4_000_000, max(probe_rows, probe_rows * args.cpu_seconds / max(t_probe, 1e-3))))
     rows = min(rows, args.rows)
     x = ko.normalize_rows(ko.synth_rows(rows, args.dim, 4))
     t0 = time.perf_counter()
     ko.search_blas(x, q, args.k)
     t = time.perf_counter() - t0
     full = t * (args.rows / rows)
-    log(f"cpu baseline: {rows} rows x {args.nq} queries in {t:.2f}s (threads={blas_threads})")
+    gflops = 2.0 * rows * args.dim * args.nq / t / 1e9
+    log(f"cpu baseline: {rows} rows x {args.nq} queries in {t:.2f}s ({gflops:.0f} GFLOP/s, BLAS threads={blas_threads})")
     return {
         "value": args.nq / full,
         "unit": "queries/s",
         "cores": int(blas_threads),
         "kind": "port",
-        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, numpy SGEMM + top-{args.k} "
-                  f"(oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
+        "achieved_GFLOPs": gflops,
+        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, blocked SGEMM (numpy BLAS, {blas_threads} threads) "
+                  f"+ heap fold in C/OpenMP (oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
     }
 
 
@@ -119,6 +128,27 @@ def pmc_traffic(kernel_prefix, workload):
         for name, v in d.get("kernels", {}).items():
             if name.startswith(kernel_prefix):
                 return {"bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "source": os.path.relpath(f, ROOT)}
+    return None
+
+
+def pmc_traffic_encoder(workload):
+    """HBM-side bytes of ONE encoder forward: every kernel's bytes summed over a profiled run of the fixed shape
+    (profiles/r*_pmc_hbm_traffic_encoder.json), divided by the number of forwards (= launches of k_embed_ln)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_encoder.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload:
+            continue
+        ks = d.get("kernels", {})
+        fw = sum(v["launches"] for k_, v in ks.items() if k_.startswith("k_embed_ln"))
+        if not fw:
+            continue
+        tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k_, v in ks.items()
+                  if k_.startswith(("k_gemm", "k_attention", "k_layernorm", "k_embed_ln", "k_pool")))
+        return {"bytes_per_forward": tot / fw, "source": os.path.relpath(f, ROOT)}
     return None
 
 
@@ -180,28 +210,39 @@ def bench_encoder(args, dev, log):
     res = {
         "chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "seq_len": L, "dtype": "bf16 MFMA, fp32 accumulate",
         "algorithmic_TFLOP_per_batch": fl / 1e12,
-        "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "kernel": "whole forward (12 x [QKV, attention, O+LN, FFN1+GELU, FFN2+LN], pooling)",
+                     "achieved": fl / dt / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": fl / dt / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None},
         "kernels": kern,
     }
+    tr = pmc_traffic_encoder({"enc_batch": B, "enc_len": L})
+    if tr:
+        res["roofline"]["traffic"] = tr["bytes_per_forward"]
+        res["roofline"]["traffic_source"] = tr["source"]
     log(f"encoder: {B}x{L} in {dt * 1e3:.2f} ms -> {B / dt:.0f} chunks/s, {fl / dt / 1e12:.0f} TFLOP/s")
     if not args.no_cpu_baseline:
         from oracle import mpnet_oracle as mo
 
         cfg = mo.MpnetCfg()
         w = mo.synth_weights(cfg, 1)
-        nb = 2
-        batch = [ids_h[i * L:(i + 1) * L].tolist() for i in range(nb)]
-        # one sequence at a time is small-matrix work: more threads than ~16 only thrash
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        # sentence-transformers' CPU default batch (src/embeddings.py:33: 16), two batches, every host core torch has
+        nb = 32
+        pick = list(range(0, B, max(1, B // nb)))[:nb]
+        batch = [ids_h[i * L:(i + 1) * L].tolist() for i in pick]
+        mo.encode_batched(w, cfg, batch[:2], batch_size=2)   # warm-up
         t0 = time.perf_counter()
-        ref = mo.encode(w, cfg, batch)
+        ref = mo.encode_batched(w, cfg, batch, batch_size=16)
         tc = time.perf_counter() - t0
-        cos = (out[:nb].cpu().numpy() * ref).sum(1)
-        res["cpu_baseline"] = {"value": nb / tc, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{nb} of the {B} sequences (L={L}) through oracle.mpnet_oracle (torch fp32)"}
+        cos = (out[pick].cpu().numpy() * ref).sum(1)
+        res["cpu_baseline"] = {"value": len(pick) / tc, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "achieved_GFLOPs": encoder_flops([L] * len(pick)) / tc / 1e9,
+                               "sample": f"{len(pick)} of the {B} sequences (L={L}), batch 16, through "
+                                         f"oracle.mpnet_oracle.encode_batched (torch fp32, {torch.get_num_threads()} threads)"}
         res["parity_vs_oracle_min_cos"] = float(cos.min())
-        log(f"encoder cpu baseline: {nb} seqs in {tc:.2f}s; min cos vs oracle {cos.min():.6f}")
+        log(f"encoder cpu baseline: {len(pick)} seqs in {tc:.2f}s; min cos vs oracle {cos.min():.6f}")
+    if args.enc_fixed_only:
+        enc.close()
+        return res
     # second shape: the chunk-length mix of config 1 (chars ~ U[100, 2000],
     # tokens = clip(round(chars / 4) + 2, 2, 384)), packed var-len, same batch size
     chars = 100 + synth.uint(11, np.arange(B, dtype=np.uint64), 0, 1901)
@@ -283,6 +324,14 @@ def bench_encoder(args, dev, log):
     return res
 
 
+def timed_steps(step, fence, nsteps):
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +352,7 @@ def main():
 
     from claude_semantic_search_amd import _native as nat
     from claude_semantic_search_amd import synth
-    from claude_semantic_search_amd.flat_index import IndexFlatIP
+    from claude_semantic_search_amd.sharded import ShardedFlatIndex
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
@@ -323,81 +372,66 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    # ---- build this rank's shard in HBM (rows generated on the device) -------
-    lo = rank * args.rows // world
-    hi = (rank + 1) * args.rows // world
-    shard = hi - lo
-    stream = torch.cuda.current_stream().cuda_stream
-    index = IndexFlatIP(args.dim, device=local_rank)
-    index.reserve(shard)
-    t0 = time.perf_counter()
-    index.add_synthetic(shard, seed=4, first_row=lo, normalize=True, stream=stream)
-    index.set_id_base(lo)
-    torch.cuda.synchronize()
-    log(f"rank0 shard: {shard} rows x {args.dim} ({shard * args.dim * 4 / 1e9:.2f} GB) generated in "
-        f"{time.perf_counter() - t0:.2f}s")
-
-    q_host = synth.rows(args.nq, args.dim, 5)
-    q = torch.from_numpy(q_host).to(dev)
-    D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
-    I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
-    if world > 1:
-        Dg = torch.empty((world, args.nq, args.k), dtype=torch.float32, device=dev)
-        Ig = torch.empty((world, args.nq, args.k), dtype=torch.int64, device=dev)
-        Dm = torch.empty_like(D)
-        Im = torch.empty_like(I)
-
-    def step():
-        index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
-        if world > 1:
-            if one_gpu:  # gloo has no device all_gather_into_tensor: stage through the host (rehearsal only)
-                dl = [torch.empty_like(D, device="cpu") for _ in range(world)]
-                il = [torch.empty_like(I, device="cpu") for _ in range(world)]
-                dist.all_gather(dl, D.cpu())
-                dist.all_gather(il, I.cpu())
-                Dg.copy_(torch.stack(dl))
-                Ig.copy_(torch.stack(il))
-            else:
-                dist.all_gather_into_tensor(Dg.view(world * args.nq, args.k), D)
-                dist.all_gather_into_tensor(Ig.view(world * args.nq, args.k), I)
-            nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dg.data_ptr()), ctypes.c_void_p(Ig.data_ptr()),
-                                                   world, args.nq, args.k, 0, ctypes.c_void_p(Dm.data_ptr()),
-                                                   ctypes.c_void_p(Im.data_ptr()), local_rank,
-                                                   ctypes.c_void_p(stream)))
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- build this rank's shard in HBM (rows generated on the device) -------
+    # weak scaling: args.rows rows PER GPU of one virtual index of args.rows * world rows (N = 8: 80 M x 768)
+    rows_total = args.rows * world
+    stream = torch.cuda.current_stream().cuda_stream
+    sh = ShardedFlatIndex(args.dim, 0, device_index=local_rank)
+    t0 = time.perf_counter()
+    sh.add_synthetic_global(rows_total, seed=4, normalize=True, stream=stream)
+    index = sh.local
+    shard = index.ntotal
+    torch.cuda.synchronize()
+    log(f"rank0 shard: {shard} of {rows_total} rows x {args.dim} ({shard * args.dim * 4 / 1e9:.2f} GB fp32) generated in "
+        f"{time.perf_counter() - t0:.2f}s")
+
+    q_host = synth.rows(args.nq, args.dim, 5)
+    q = torch.from_numpy(q_host).to(dev)
+    result = {}
+
+    def step():
+        result["DI"] = sh.search_tensors(q, args.k, normalize=True)
 
     for _ in range(args.warmup):
         step()
     fence()
     nat.prof_reset()
     nat.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, fence, args.steps)
     nat.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     qps = args.nq * args.steps / elapsed
+    D, I = result["DI"]
+    assert D.shape == (args.nq, args.k) and bool((I >= 0).all()) and bool((I < rows_total).all())
+    assert bool((D[:, 1:] <= D[:, :-1]).all())
+    if world > 1:   # every shard contributes to the merged answer
+        owners = torch.bincount((I.flatten() // args.rows).clamp_(max=world - 1), minlength=world)
+        assert int((owners > 0).sum()) == world, owners.tolist()
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
     kernels = {}
-    for name in ("knn_scan_coarse_main", "knn_coarse_cascade", "knn_scan_mfma", "knn_scan_small", "knn_merge",
-                 "knn_merge_parts"):
+    for name in ("knn_scan_coarse_main", "knn_coarse_cascade", "knn_scan_mfma", "knn_scan_split", "knn_scan_small",
+                 "knn_fix_scan", "knn_merge", "knn_merge_parts"):
         ms, n = nat.prof_read(name)
         if n:
             kernels[name] = (ms, n)
     cand = {k_: v for k_, v in kernels.items() if k_ != "knn_coarse_cascade"}
     dom = max(cand, key=lambda k_: cand[k_][0]) if cand else None
     roofline = None
+    wl = {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k}
     if dom:
         ms, n = kernels[dom]
         avg_s = ms / n / 1e3
@@ -422,35 +456,22 @@ def main():
                 cms, cn = kernels["knn_coarse_cascade"]
                 roofline["cascade_ms"] = cms / cn           # all stages + selects + rescoring of one search
                 roofline["cascade_algorithmic_TFLOPs"] = 2.0 * shard * args.dim * args.nq / (cms / cn / 1e3) / 1e12
-        elif dom == "knn_scan_mfma":
-            nq_launch = args.nq * args.steps / n     # queries served per launch
-            flops = 2.0 * shard * args.dim * nq_launch   # ALGORITHMIC (fp32 dot-product) flops
-            split = os.environ.get("CSS_KNN_BATCH", "split") != "fp32"
-            # split mode: every fp32-grade product costs 3 bf16 MFMA products (h.h + h.l + l.h), so the
-            # roof of the emulation is the dense bf16 peak / 3; fp32 mode: the fp32-input MFMA peak.
-            peak = BF16_MFMA_PEAK_TF / 3.0 if split else FP32_MFMA_PEAK_TF
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": flops / avg_s / 1e12, "peak": peak,
-                        "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": None,
-                        "launches": n, "avg_ms": ms / n, "hbm_GBps": sweep_bytes / avg_s / 1e9,
-                        "arithmetic": ("bf16x3 split-operand MFMA, fp32 accumulate (peak = 2500/3)" if split
-                                       else "fp32-input MFMA (exact fp32)"),
-                        "executed_mfma_TFLOPs": (3.0 if split else 1.0) * flops * (-(-args.nq // 128) * 128 / args.nq) / avg_s / 1e12}
         else:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": sweep_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": sweep_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "launches": n, "avg_ms": ms / n}
-    if roofline:
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
-        wl = {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k}
-        tr = pmc_traffic({"knn_scan_mfma": "k_scan_mfma", "knn_scan_coarse_main": "k_scan_coarse<false, true"}.get(dom, "k_scan_small"), wl)
+        tr = pmc_traffic({"knn_scan_coarse_main": "k_scan_coarse<false, true"}.get(dom, "k_scan_small"), wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
             roofline["algorithmic_bytes_per_launch"] = sweep_bytes
     nat.prof_reset()
 
-    # ---- extra: the reference's real call shape (one query, k'=100) -------------
+    # ---- the reference's real call shape: one query per call (k = 10 and k' = 100) -------------
     extra = {}
+    D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+    I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
     if not args.no_extra:
         D1 = torch.empty((1, 100), dtype=torch.float32, device=dev)
         I1 = torch.empty((1, 100), dtype=torch.int64, device=dev)
@@ -479,17 +500,21 @@ def main():
                 kname = "k_scan_small<1,"
             gbs = kbytes / (ms / n / 1e3) / 1e9 if n else None
             cms, cn = nat.prof_read("knn_sweep_cascade")
-            tr = pmc_traffic(kname, {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
-            extra[f"nq1_k{kq}"] = {"latency_ms": dt * 1e3, "cascade_ms": cms / cn if cn else None,
-                                   "scan_kernel_ms": ms / n if n else None,
-                                   "roofline": {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
-                                                "traffic": tr["bytes_per_launch"] if tr else None,
-                                                "algorithmic_bytes_per_launch": kbytes},
-                                   "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
+            tr = pmc_traffic(kname, wl)
+            rec = {"bound": "hbm", "kernel": kname + " (main stage of the single-query cascade)", "achieved": gbs,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                   "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": kbytes,
+                   "latency_ms": dt * 1e3, "cascade_ms": cms / cn if cn else None, "scan_kernel_ms": ms / n if n else None,
+                   # the whole call against the bytes it has to read (all bf16 rows once): the end-to-end HBM fraction
+                   "whole_call_GBps": shard * args.dim * 2 / dt / 1e9,
+                   "whole_call_frac_of_peak": shard * args.dim * 2 / dt / 1e9 / HBM_PEAK_GBS,
+                   "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
+            if kq == 10 and roofline is not None:
+                roofline["nq1_k10"] = rec
+            extra[f"nq1_k{kq}"] = rec
             nat.prof_reset()
 
-        # ---- extra: masked search (filter / tombstone push-down), half of the rows allowed ----
+        # ---- masked search (filter / tombstone push-down), half of the rows allowed ----
         words = (shard + 31) // 32
         mbits = torch.full((words,), 0x55555555, dtype=torch.int32, device=dev)   # every other row
         mk = {}
@@ -504,11 +529,12 @@ def main():
                                  allow_bits_ptr=mbits.data_ptr())
             fence()
             dt = (time.perf_counter() - t0) / reps
-            assert bool((I[:nqm] % 2 == 0).all())
+            assert bool(((I[:nqm] - index_id_base(sh)) % 2 == 0).all())
             mk[f"nq{nqm}_k{args.k}"] = {"ms": dt * 1e3, "queries_per_s": nqm / dt}
         extra["masked_half_rows"] = mk
+        del mbits
 
-        # ---- extra: the parity mode (every score formed in fp32 by the scan kernels) on the same index ----
+        # ---- the parity mode: every score formed by fp32 fmaf chains inside the scan kernels ----
         index.set_search_mode("exact_fp32")
         try:
             ex = {}
@@ -525,42 +551,68 @@ def main():
             nat.prof_enable(False)
             ms, n = nat.prof_read("knn_scan_small")
             gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
-            tr = pmc_traffic("k_scan_small<1,", {"rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k})
-            ex["nq1_k10"] = {"latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
-                             "roofline": {"bound": "hbm", "kernel": "k_scan_small<1,12,IP>", "achieved": gbs,
-                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
-                                          "traffic": tr["bytes_per_launch"] if tr else None,
-                                          "algorithmic_bytes_per_launch": shard * args.dim * 4}}
+            tr = pmc_traffic("k_scan_small<1,", wl)
+            ex["nq1_k10"] = {"bound": "hbm", "kernel": "k_scan_small<1,12,IP> (fp32 VALU sweep)", "achieved": gbs,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                             "traffic": tr["bytes_per_launch"] if tr else None,
+                             "algorithmic_bytes_per_launch": shard * args.dim * 4,
+                             "latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
             nat.prof_reset()
-            index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            nqe = min(args.nq, 256)   # the fp32-input MFMA scan is 16x slower per flop than bf16: a quarter batch
+            index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
             fence()
             nat.prof_enable(True)
             t0 = time.perf_counter()
-            for _ in range(2):
-                index.search_dev(q.data_ptr(), args.nq, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+            index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
             fence()
-            dt = (time.perf_counter() - t0) / 2
+            dt = time.perf_counter() - t0
             nat.prof_enable(False)
             ms, n = nat.prof_read("knn_scan_mfma")
-            fl = 2.0 * shard * args.dim * args.nq
-            ex[f"nq{args.nq}_k{args.k}"] = {
-                "queries_per_s": args.nq / dt, "ms_per_batch": dt * 1e3, "scan_kernel_ms": ms / n if n else None,
-                "roofline": {"bound": "mfma", "kernel": "k_scan_mfma_split<IP,8,8>",
-                             "achieved": fl / (ms / n / 1e3) / 1e12 if n else None, "peak": BF16_MFMA_PEAK_TF / 3.0,
-                             "unit": "TFLOP/s", "frac": fl / (ms / n / 1e3) / 1e12 / (BF16_MFMA_PEAK_TF / 3.0) if n else None,
-                             "arithmetic": "fp32 operands split into bf16 pairs, 3 MFMA products per fp32-grade product"}}
+            fl = 2.0 * shard * args.dim * nqe
+            tr = pmc_traffic("k_scan_mfma<", wl)
+            ex[f"nq{nqe}_k{args.k}"] = {
+                "bound": "mfma", "kernel": "k_scan_mfma<IP> (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chains)",
+                "achieved": fl / (ms / n / 1e3) / 1e12 if n else None, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": fl / (ms / n / 1e3) / 1e12 / FP32_MFMA_PEAK_TF if n else None,
+                "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": shard * args.dim * 4,
+                "queries_per_s": nqe / dt, "ms_per_batch": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
             nat.prof_reset()
             extra["exact_fp32_mode"] = ex
+            if roofline is not None:
+                roofline["exact_fp32_mode"] = ex
         finally:
             index.set_search_mode("auto")
+
+    # ---- N > 1: strong scaling of the fixed args.rows-row index on the same ranks ----
+    strong = None
+    if world > 1 and not args.no_strong:
+        sh.local.close()
+        sh2 = ShardedFlatIndex(args.dim, 0, device_index=local_rank)
+        sh2.add_synthetic_global(args.rows, seed=4, normalize=True, stream=stream)
+        for _ in range(max(2, args.warmup)):
+            sh2.search_tensors(q, args.k, normalize=True)
+        fence()
+        ns = max(args.steps, 5)
+        el = max_over_ranks(timed_steps(lambda: sh2.search_tensors(q, args.k, normalize=True), fence, ns))
+        strong = {"rows_total": args.rows, "rows_per_gpu": sh2.local.ntotal, "ms_per_step": el / ns * 1e3,
+                  "queries_per_s": args.nq * ns / el, "scaling": "strong"}
+        sh2.local.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_knn(args, log)
+
+    # ---- clustered rows: how much of the throughput survives dense candidate bands (flagged fraction) ----
+    if world == 1 and not args.no_extra:
+        try:
+            extra["clustered_1M"] = bench_clustered(args, dev, stream, log)
+        except Exception as ex_:   # an extra: never fail the bench line over it
+            extra["clustered_1M"] = {"error": repr(ex_)}
+
     if not args.no_encoder:
         index.close()  # free the shard before the encoder leg
         if world == 1:
-            extra["encode"] = bench_encoder(args, dev, log)
+            enc = bench_encoder(args, dev, log)
         else:
             # encoder: replicas only (weights replicated, one batch per rank, no collective in the path)
             args.no_cpu_baseline = True
@@ -572,13 +624,26 @@ def main():
             enc["chunks_per_s_all_ranks"] = float(tsum[0].item())
             enc["ms_per_batch_max_over_ranks"] = float(t[1].item())
             enc["parallelism"] = f"{world} replicas, no collective"
-            extra["encode"] = enc
+        extra["encode"] = enc
+        if roofline is not None:
+            er = dict(enc["roofline"])
+            er.update(chunks_per_s=enc.get("chunks_per_s_all_ranks", enc["chunks_per_s"]), ms_per_batch=enc["ms_per_batch"],
+                      batch=enc["batch"], seq_len=enc["seq_len"], algorithmic_TFLOP_per_batch=enc["algorithmic_TFLOP_per_batch"],
+                      length_mix_chunks_per_s=enc.get("length_mix", {}).get("chunks_per_s"),
+                      parity_vs_oracle_min_cos=enc.get("parity_vs_oracle_min_cos"))
+            roofline["encode"] = er
+        if cpu is not None and "cpu_baseline" in enc:
+            cpu["encode"] = enc["cpu_baseline"]
 
     if world > 1:
         dist.barrier()
     if rank == 0:
+        cfg_name = ("BASELINE configs[3]: 10Mx768 index on 1 MI355X, 1k-query batch top-10" if world == 1 and args.rows == 10_000_000
+                    else f"BASELINE configs[4] shape: {rows_total}x{args.dim} index sharded over {world} MI355X "
+                         f"({args.rows} rows per GPU), all-gather of per-shard top-k")
         out = {
-            "metric": "queries/sec@top-10 over 10Mx768 flat index (1k-query batch)",
+            "metric": f"queries/sec@top-{args.k} over Nx{args.dim} flat index ({args.nq}-query batch); "
+                      "chunks embedded/sec in roofline.encode",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -586,15 +651,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (index, queries and returned scores fp32; candidate selection by a bf16 MFMA scan with a "
                      "rigorous error band, candidates rescored in fp32)",
             "data": "synthetic",
-            "config": {"workload": f"{args.rows}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
-                                   f"top-{args.k}, index row-partitioned over {world} GPU(s)",
-                       "rows_total": args.rows, "rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k,
-                       "parallelism": f"row-shard x{world} + all-gather(top-k)"},
+            "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
+                                   f"top-{args.k}, {args.rows} rows per GPU",
+                       "rows_total": rows_total, "rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k,
+                       "parallelism": f"row-shard x{world} + one packed all-gather(top-k) + merge (ShardedFlatIndex)",
+                       "strong_10M": strong},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extra": extra,
@@ -602,6 +668,67 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def index_id_base(sh):
+    """Global id of this shard's local row 0 (one segment: the synthetic bench index)."""
+    return sh.segments[0][1] - sh.segments[0][0] if sh.segments else 0
+
+
+def bench_clustered(args, dev, stream, log):
+    """1 M rows in 2000 tight clusters (the generator of tests/test_fullsize_gpu.py): queries near cluster centres
+    have hundreds of rows inside the bf16 error band.  Reports throughput of the product path, how many queries
+    overflowed band or buffer (and were re-run exactly by the device-side fix-up), next to uniform rows of the same size."""
+    import numpy as np
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, nc, d = 1_000_000, 2000, args.dim
+    cent = synth.rows(nc, d, 71)
+    out = {}
+    for name in ("clustered", "uniform"):
+        ix = IndexFlatIP(d, device=dev.index or 0)
+        ix.reserve(n)
+        if name == "uniform":
+            ix.add_synthetic(n, seed=4, first_row=0, normalize=True, stream=stream)
+            qh = synth.rows(args.nq, d, 5)
+        else:
+            for c0 in range(0, n, 250_000):
+                ids = np.arange(c0, c0 + 250_000) % nc
+                ix.add(cent[ids] + 0.05 * synth.rows(250_000, d, 72 + c0 // 250_000), normalize=True)
+            near = cent[np.arange(args.nq * 2 // 3) % nc] + 0.02 * synth.rows(args.nq * 2 // 3, d, 90)
+            qh = np.concatenate([near, synth.rows(args.nq - near.shape[0], d, 91)])
+        qd = torch.from_numpy(np.ascontiguousarray(qh, dtype=np.float32)).to(dev)
+        Dd = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+        Id = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ix.search_dev(qd.data_ptr(), args.nq, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+        torch.cuda.synchronize()
+        nat.prof_reset()
+        nat.prof_enable(True)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ix.search_dev(qd.data_ptr(), args.nq, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        nat.prof_enable(False)
+        fms, fn = nat.prof_read("knn_fix_scan")
+        cms, cn = nat.prof_read("knn_coarse_cascade")
+        nat.prof_reset()
+        flagged = ix.last_flagged()
+        out[name] = {"queries_per_s": args.nq / dt, "ms_per_batch": dt * 1e3, "cascade_ms": cms / cn if cn else None,
+                     "flagged_queries": flagged, "flagged_fraction": flagged / args.nq,
+                     "fixup_scan_ms": fms / fn if fn else None}
+        ix.close()
+    out["note"] = ("fixup_scan_ms is the device-side exact re-run of flagged queries (about 2 us when none is flagged: "
+                   "the launch returns at once)")
+    log(f"clustered 1M: {out['clustered']['queries_per_s']:.0f} q/s ({out['clustered']['flagged_queries']} flagged) vs "
+        f"uniform {out['uniform']['queries_per_s']:.0f} q/s")
+    return out
 
 
 if __name__ == "__main__":

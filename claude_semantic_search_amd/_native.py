@@ -82,6 +82,7 @@ PROTOTYPES = {
     "css_index_metric": (c_int, [c_void_p, POINTER(c_int)]),
     "css_index_device": (c_int, [c_void_p, POINTER(c_int)]),
     "css_index_set_shadow": (c_int, [c_void_p, c_int]),
+    "css_index_last_flagged": (c_int, [c_void_p, POINTER(c_int64)]),
     "css_index_set_id_base": (c_int, [c_void_p, c_int64]),
     "css_index_set_search_mode": (c_int, [c_void_p, c_int]),
     "css_index_add": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
@@ -94,6 +95,8 @@ PROTOTYPES = {
     "css_index_search_masked_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                             c_void_p]),
     "css_merge_topk_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "css_merge_topk_packed_dev": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                          c_void_p]),
     "css_encoder_create": (c_int, [POINTER(EncoderCfg), c_int, POINTER(c_void_p)]),
     "css_encoder_free": (c_int, [c_void_p]),
     "css_encoder_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int]),

@@ -485,7 +485,9 @@ int css_encoder_load_weights(css_encoder* e, const css_tensor* tensors, int n) {
     CSS_REQUIRE(e && tensors && n >= 0, "css_encoder_load_weights: bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
-    int loaded = 0;
+    // A checkpoint must cover every parameter exactly once: a missing tensor would leave uninitialised device
+    // memory in the model, a duplicate (the same key under two prefixes) makes the result depend on the order.
+    std::map<std::string, int> seen;
     for (int i = 0; i < n; ++i) {
         CSS_REQUIRE(tensors[i].name && tensors[i].data, "css_encoder_load_weights: tensor %d has NULL name/data", i);
         std::string name = tensors[i].name;
@@ -497,10 +499,30 @@ int css_encoder_load_weights(css_encoder* e, const css_tensor* tensors, int n) {
         CSS_REQUIRE(it != e->params.end(), "css_encoder_load_weights: unknown parameter '%s'", name.c_str());
         CSS_REQUIRE(it->second.numel == tensors[i].numel, "css_encoder_load_weights: '%s' has %lld elements, expected %lld",
                     name.c_str(), (long long)tensors[i].numel, (long long)it->second.numel);
+        CSS_REQUIRE(seen[name]++ == 0, "css_encoder_load_weights: parameter '%s' appears more than once", name.c_str());
         CSS_HIP_TRY(hipMemcpy(it->second.p, tensors[i].data, (size_t)tensors[i].numel * 4, hipMemcpyHostToDevice));
-        ++loaded;
     }
-    (void)loaded;
+    for (const auto& kv : e->params) {
+        const std::string& nm = kv.first;
+        const bool view = nm.find(".attn.q.") != std::string::npos || nm.find(".attn.k.") != std::string::npos ||
+                          nm.find(".attn.v.") != std::string::npos;
+        const size_t fq = nm.find(".attn.qkv.");
+        if (fq != std::string::npos) {
+            // fused [3H, H] weight / [3H] bias: given as one tensor, or as its three HF views q, k, v -- not both
+            int parts = 0;
+            for (const char* v : {"q", "k", "v"}) {
+                std::string vn = nm;
+                vn.replace(fq, 10, std::string(".attn.") + v + ".");
+                parts += seen.count(vn) ? 1 : 0;
+            }
+            const bool whole = seen.count(nm) != 0;
+            CSS_REQUIRE(!(whole && parts > 0), "css_encoder_load_weights: '%s' given both fused and as q/k/v", nm.c_str());
+            CSS_REQUIRE(whole || parts == 3, "css_encoder_load_weights: checkpoint does not cover '%s' (q/k/v: %d of 3)",
+                        nm.c_str(), parts);
+        } else if (!view) {
+            CSS_REQUIRE(seen.count(nm) != 0, "css_encoder_load_weights: checkpoint has no tensor for '%s'", nm.c_str());
+        }
+    }
     return finalize_weights(e);
 }
 

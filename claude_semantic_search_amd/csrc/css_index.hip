@@ -78,6 +78,7 @@ struct css_index {
     // export wait for this event before touching rows, norms or maxn2
     hipEvent_t ingest_ev = nullptr;
     bool ingest_pending = false;
+    const int* last_nflag = nullptr;   // device counter of the last candidate-path search (css_index_last_flagged)
     std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
     std::mutex ws_mu;      // workspaces + own stream are single-user
 };
@@ -1085,10 +1086,12 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
 }
 
 // Merge of per-shard final results with global int64 ids (multi-GPU exchange).
+// Part p holds its [nq, k] scores at Dp + p * stride_d and its ids at Ip + p * stride_i (elements): dense
+// [nparts, nq, k] arrays, or the packed exchange records of the sharded search ([ids | scores] per rank).
 template <int METRIC>
 __global__ __launch_bounds__(64) void k_merge_parts(const float* __restrict__ Dp, const int64_t* __restrict__ Ip,
-                                                    int nparts, int64_t nq, int k, float* __restrict__ D,
-                                                    int64_t* __restrict__ I) {
+                                                    int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
+                                                    float* __restrict__ D, int64_t* __restrict__ I) {
     __shared__ float fs[CSS_MAX_K];
     __shared__ int64_t fi[CSS_MAX_K];
     const int64_t q = blockIdx.x;
@@ -1099,10 +1102,10 @@ __global__ __launch_bounds__(64) void k_merge_parts(const float* __restrict__ Dp
     }
     for (int p = 0; p < nparts; ++p)
         for (int j = 0; j < k; ++j) {
-            const size_t o = ((size_t)p * nq + q) * k + j;
-            const int64_t id = Ip[o];
+            const size_t o = (size_t)q * k + j;
+            const int64_t id = Ip[(size_t)p * stride_i + o];
             if (id < 0) continue;  // wave uniform
-            float s = Dp[o];
+            float s = Dp[(size_t)p * stride_d + o];
             if (METRIC == CSS_METRIC_L2) s = -s;
             wave_insert<int64_t>(fs, fi, k, s, id, lane);
         }
@@ -1348,6 +1351,7 @@ int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
     int rc;
     if ((rc = grow(&ix->cthr, &ix->cthr_cap, nq_pad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, nq_pad)) != CSS_OK) return rc;
+    ix->last_nflag = nullptr;
     if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 1)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
@@ -1438,6 +1442,7 @@ int launch_scan_split_rescore(css_index* ix, int nq, int k, float* D_dev, int64_
     int* flags = ix->cflags;
     int* flag_list = ix->cflags + nq_pad;
     int* nflag = ix->cflags + 2 * nq_pad;
+    ix->last_nflag = nflag;
     if (nq_pad > nq)
         CSS_HIP_TRY(hipMemsetAsync(ix->qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad, host_f2key(-INFINITY));
@@ -1529,6 +1534,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     int* flags = ix->cflags;
     int* flag_list = ix->cflags + nq_pad;
     int* nflag = ix->cflags + 2 * nq_pad;
+    ix->last_nflag = nflag;
 
     // cascade schedule: stage 0 reads every s0-th row tile (2..7 tiles), then strides s0/4 ... 1
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
@@ -1795,6 +1801,20 @@ int css_index_set_search_mode(css_index* ix, int mode) {
     return CSS_OK;
 }
 
+int css_index_last_flagged(css_index* ix, int64_t* n) {
+    CSS_REQUIRE(ix && n, "css_index_last_flagged: NULL argument");
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);
+    *n = 0;
+    if (ix->last_nflag == nullptr) return CSS_OK;
+    DeviceGuard g(ix->device);
+    CSS_HIP_TRY(hipDeviceSynchronize());  // diagnostics: whichever stream the search ran on
+    int v = 0;
+    CSS_HIP_TRY(hipMemcpy(&v, ix->last_nflag, sizeof(int), hipMemcpyDeviceToHost));
+    *n = v;
+    return CSS_OK;
+}
+
 int css_index_set_shadow(css_index* ix, int policy) {
     CSS_REQUIRE(ix, "css_index_set_shadow: NULL index");
     CSS_REQUIRE(policy >= -1 && policy <= 1, "css_index_set_shadow: policy %d outside {-1, 0, 1}", policy);
@@ -1973,11 +1993,12 @@ int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int 
     return css_index_search_masked(ix, q_host, nq, k, normalize_q, nullptr, D_host, I_host);
 }
 
-int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t nq, int k, int metric, float* D,
-                       int64_t* I, int device, void* stream) {
-    CSS_REQUIRE(Dp && Ip && D && I, "css_merge_topk_dev: NULL buffer");
-    CSS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= CSS_MAX_K, "css_merge_topk_dev: bad sizes");
-    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "css_merge_topk_dev: unknown metric");
+namespace {
+int merge_parts(const float* Dp, const int64_t* Ip, int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
+                int metric, float* D, int64_t* I, int device, void* stream, const char* who) {
+    CSS_REQUIRE(Dp && Ip && D && I, "%s: NULL buffer", who);
+    CSS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= CSS_MAX_K, "%s: bad sizes", who);
+    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "%s: unknown metric", who);
     int rc = css::check_device(device);
     if (rc != CSS_OK) return rc;
     if (nq == 0) return CSS_OK;
@@ -1985,11 +2006,31 @@ int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t n
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps("knn_merge_parts", st);
     if (metric == CSS_METRIC_IP)
-        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, nq, k, D, I);
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
+                           stride_i, nq, k, D, I);
     else
-        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, nq, k, D, I);
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
+                           stride_i, nq, k, D, I);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
+}
+}  // namespace
+
+int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t nq, int k, int metric, float* D,
+                       int64_t* I, int device, void* stream) {
+    return merge_parts(Dp, Ip, nparts, nq * k, nq * k, nq, k, metric, D, I, device, stream, "css_merge_topk_dev");
+}
+
+int css_merge_topk_packed_dev(const void* packed, int nparts, int64_t record_bytes, int64_t nq, int k, int metric,
+                              float* D, int64_t* I, int device, void* stream) {
+    CSS_REQUIRE(packed != nullptr, "css_merge_topk_packed_dev: NULL buffer");
+    CSS_REQUIRE(nq >= 0 && k >= 1 && record_bytes >= 12 * nq * k && record_bytes % 8 == 0,
+                "css_merge_topk_packed_dev: record of %lld bytes cannot hold [%lld x %d] ids and scores (multiple of 8)",
+                (long long)record_bytes, (long long)nq, k);
+    const int64_t* Ip = reinterpret_cast<const int64_t*>(packed);
+    const float* Dp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + 8 * nq * k);
+    return merge_parts(Dp, Ip, nparts, record_bytes / 4, record_bytes / 8, nq, k, metric, D, I, device, stream,
+                       "css_merge_topk_packed_dev");
 }
 
 }  // extern "C"

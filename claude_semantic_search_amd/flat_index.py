@@ -143,6 +143,12 @@ class IndexFlat:
             raise ValueError(f"unknown search mode {mode!r}")
         nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))
 
+    def last_flagged(self) -> int:
+        """Diagnostics: queries of the last candidate-path search that were re-run by the exact fix-up."""
+        n = ctypes.c_int64(0)
+        nat.check(nat.lib().css_index_last_flagged(self._handle(), ctypes.byref(n)))
+        return int(n.value)
+
     def set_shadow(self, policy: Optional[bool]) -> None:
         """bf16 shadow rows (operand of the candidate scans, +50 % HBM): ``None`` = keep them while they
         fit (default), ``False`` = never, ``True`` = always.  Only on an empty index; results do not change."""

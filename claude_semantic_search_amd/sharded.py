@@ -1,23 +1,30 @@
 """Row-partitioned flat index across the GPUs of one node.
 
-One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).
-Rank ``r`` of ``G`` owns the contiguous global rows ``[r*N/G, (r+1)*N/G)`` in its
-own HBM as an ordinary ``IndexFlat`` with ``id_base`` = first global row.  A
-search is: every rank sweeps its shard for the (replicated) query batch -> ONE
-all-gather of the per-shard top-k (``nq*k*12`` bytes per rank, latency bound,
-nothing bulky ever crosses xGMI) -> every rank merges the ``G*k`` candidates per
-query by (score, id).  There is no reference counterpart (the reference pins
-faiss to device 0, ``src/storage.py:283``); semantics are those of one big
-``IndexFlat`` and are tested as such.
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).  Every rank keeps its rows in its
+own HBM as an ordinary ``IndexFlat``.  A search is: every rank sweeps its shard for the (replicated) query batch
+-> ONE all-gather of the per-shard top-k, ids and scores packed into a single buffer of ``nq*k*12`` bytes per
+rank (latency bound, nothing bulky ever crosses xGMI) -> every rank merges the ``G*k`` candidates per query by
+(score, id).  There is no reference counterpart (the reference pins faiss to device 0, ``src/storage.py:283``);
+semantics are those of one big ``IndexFlat`` and are tested as such.
 
-The communication skeleton is backend agnostic (the CPU tests run it over gloo
-with test doubles for the device pieces); the product wiring uses device
-buffers end to end.
+Rows enter through collective calls (every rank passes the same arguments, no communication needed):
+
+* ``add_global(x)`` / ``add_synthetic_global(n)``: the call's rows are split into ``world`` contiguous blocks,
+  rank ``r`` keeps block ``r``;
+* ``add_routed(x)``: an incremental add (a file's worth of chunks) goes whole to the least-full shard.
+
+Global ids are insertion order over the calls, exactly as one ``IndexFlat`` would number them
+(``src/storage.py:358-365``).  A shard therefore holds a list of segments ``(local_row0, global_row0, n)``; with one
+segment the library's ``id_base`` does the translation inside the search kernels, with several the local ids are
+mapped through the segment table after the local search.
+
+The communication skeleton is backend agnostic (the CPU tests run it over gloo with test doubles for the device
+pieces); the product wiring uses device buffers end to end.
 """
 from __future__ import annotations
 
 import ctypes
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
@@ -27,12 +34,18 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * n_total // world, (rank + 1) * n_total // world
 
 
+def packed_layout(nq: int, k: int) -> Tuple[int, int, int]:
+    """Per-rank exchange record: ``[nq*k int64 ids][nq*k float32 scores]`` padded to 16 bytes.
+    Returns (bytes of the id part, bytes of ids + scores, padded record size)."""
+    n = nq * k
+    return 8 * n, 12 * n, (12 * n + 15) // 16 * 16
+
+
 class ShardedFlatIndex:
     """``IndexFlat`` semantics over ``world`` row shards.
 
-    ``local_index`` must offer ``ntotal``, ``add(x, normalize=)``,
-    ``add_synthetic``, ``set_id_base`` and ``search_dev``/``search``;
-    ``merge`` merges ``[world, nq, k]`` candidate tensors.  Defaults are the HIP
+    ``local_index`` must offer ``ntotal``, ``add(x, normalize=)``, ``add_synthetic``, ``set_id_base`` and
+    ``search_dev``/``search``; ``merge`` merges ``[world, nq, k]`` candidate tensors.  Defaults are the HIP
     implementations; tests substitute doubles.
     """
 
@@ -51,39 +64,93 @@ class ShardedFlatIndex:
 
             index_factory = lambda: IndexFlat(self.d, self.metric, device=device_index or 0)  # noqa: E731
         self.local = index_factory()
-        self._merge = merge or self._merge_hip
+        self._merge = merge      # None: the HIP merge straight from the packed exchange buffer
         self.ntotal_global = 0
+        self.shard_sizes = [0] * self.world          # replicated bookkeeping (all adds are collective calls)
+        self.segments: List[Tuple[int, int, int]] = []   # (local_row0, global_row0, n) of THIS shard
+        self._seg_tensors = None
 
     # -- building ----------------------------------------------------------
+    def _append_segment(self, n_local: int, global_row0: int) -> None:
+        if n_local <= 0:
+            return
+        local_row0 = self.shard_sizes[self.rank]
+        if self.segments and self.segments[-1][0] + self.segments[-1][2] == local_row0 and \
+                self.segments[-1][1] + self.segments[-1][2] == global_row0:
+            l0, g0, n0 = self.segments[-1]
+            self.segments[-1] = (l0, g0, n0 + n_local)       # contiguous in both numberings: one segment
+        else:
+            self.segments.append((local_row0, global_row0, n_local))
+        # one segment: the kernels add id_base themselves; several: local ids, translated after the search
+        self.local.set_id_base(self.segments[0][1] - self.segments[0][0] if len(self.segments) == 1 else 0)
+        self._seg_tensors = None
+
+    def _account(self, counts: List[int], n_call: int) -> None:
+        for r, c in enumerate(counts):
+            self.shard_sizes[r] += c
+        self.ntotal_global += n_call
+
     def add_global(self, x: np.ndarray, normalize: bool = False) -> None:
-        """Every rank passes the same full ``x``; each keeps its own row block."""
-        lo, hi = shard_bounds(x.shape[0], self.world, self.rank)
-        if self.local.ntotal == 0:
-            self.local.set_id_base(self.ntotal_global + lo)
-        self.local.add(np.ascontiguousarray(x[lo:hi]), normalize=normalize)
-        self.ntotal_global += x.shape[0]
+        """Every rank passes the same full ``x``; rank r keeps the r-th contiguous block of the call's rows."""
+        n = int(x.shape[0])
+        bounds = [shard_bounds(n, self.world, r) for r in range(self.world)]
+        lo, hi = bounds[self.rank]
+        if hi > lo:
+            self.local.add(np.ascontiguousarray(x[lo:hi]), normalize=normalize)
+        self._append_segment(hi - lo, self.ntotal_global + lo)
+        self._account([b[1] - b[0] for b in bounds], n)
+
+    def add_routed(self, x: np.ndarray, normalize: bool = False) -> int:
+        """Incremental add: the whole call goes to the least-full shard (lowest rank on ties).  Returns that rank."""
+        n = int(x.shape[0])
+        target = min(range(self.world), key=lambda r: (self.shard_sizes[r], r))
+        if n and target == self.rank:
+            self.local.add(np.ascontiguousarray(x), normalize=normalize)
+            self._append_segment(n, self.ntotal_global)
+        counts = [0] * self.world
+        counts[target] = n
+        self._account(counts, n)
+        return target
 
     def add_synthetic_global(self, n_total: int, seed: int, normalize: bool = True, stream: int = 0) -> None:
-        lo, hi = shard_bounds(n_total, self.world, self.rank)
-        self.local.reserve(hi - lo)
-        self.local.add_synthetic(hi - lo, seed, first_row=lo, normalize=normalize, stream=stream)
-        self.local.set_id_base(lo)
-        self.ntotal_global = n_total
+        """Rows of the virtual synthetic index (``css_synth.h``, row r is the same vector wherever it lives)."""
+        bounds = [shard_bounds(n_total, self.world, r) for r in range(self.world)]
+        lo, hi = bounds[self.rank]
+        if self.shard_sizes[self.rank] == 0:
+            self.local.reserve(hi - lo)
+        if hi > lo:
+            self.local.add_synthetic(hi - lo, seed, first_row=lo, normalize=normalize, stream=stream)
+        self._append_segment(hi - lo, self.ntotal_global + lo)
+        self._account([b[1] - b[0] for b in bounds], n_total)
+
+    # -- id translation ------------------------------------------------------
+    def _to_global(self, I):
+        """Local row numbers -> global ids through the segment table (only needed with several segments)."""
+        import torch
+
+        if len(self.segments) <= 1:
+            return I
+        if self._seg_tensors is None or self._seg_tensors[0].device != I.device:
+            l0 = torch.tensor([s[0] for s in self.segments], dtype=torch.int64, device=I.device)
+            g0 = torch.tensor([s[1] for s in self.segments], dtype=torch.int64, device=I.device)
+            self._seg_tensors = (l0, g0)
+        l0, g0 = self._seg_tensors
+        seg = (torch.bucketize(I, l0, right=True) - 1).clamp_(min=0)
+        return torch.where(I >= 0, I - l0[seg] + g0[seg], I)
 
     # -- searching ---------------------------------------------------------
-    def _merge_hip(self, Dg, Ig, k: int):
+    def _merge_packed_hip(self, recv, nq: int, k: int, record: int):
         import torch
 
         from . import _native as nat
 
-        nq = Dg.shape[1]
-        Dm = torch.empty((nq, k), dtype=torch.float32, device=Dg.device)
-        Im = torch.empty((nq, k), dtype=torch.int64, device=Dg.device)
+        Dm = torch.empty((nq, k), dtype=torch.float32, device=recv.device)
+        Im = torch.empty((nq, k), dtype=torch.int64, device=recv.device)
         st = torch.cuda.current_stream().cuda_stream
-        nat.check(nat.lib().css_merge_topk_dev(ctypes.c_void_p(Dg.data_ptr()), ctypes.c_void_p(Ig.data_ptr()),
-                                               self.world, nq, k, self.metric, ctypes.c_void_p(Dm.data_ptr()),
-                                               ctypes.c_void_p(Im.data_ptr()), Dg.device.index or 0,
-                                               ctypes.c_void_p(st)))
+        nat.check(nat.lib().css_merge_topk_packed_dev(ctypes.c_void_p(recv.data_ptr()), self.world, record, nq, k,
+                                                      self.metric, ctypes.c_void_p(Dm.data_ptr()),
+                                                      ctypes.c_void_p(Im.data_ptr()), recv.device.index or 0,
+                                                      ctypes.c_void_p(st)))
         return Dm, Im
 
     def search_tensors(self, q, k: int, normalize: bool = False):
@@ -92,8 +159,11 @@ class ShardedFlatIndex:
         import torch
 
         nq = q.shape[0]
-        D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-        I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        ib, db, record = packed_layout(nq, k)
+        # the local result is written straight into this rank's exchange record: [ids | scores]
+        send = torch.empty(record, dtype=torch.uint8, device=q.device)
+        I = send[:ib].view(torch.int64).view(nq, k)
+        D = send[ib:db].view(torch.float32).view(nq, k)
         if q.is_cuda:
             st = torch.cuda.current_stream().cuda_stream
             self.local.search_dev(q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), st, normalize=normalize)
@@ -101,15 +171,25 @@ class ShardedFlatIndex:
             d_np, i_np = self.local.search(q.numpy(), k, normalize=normalize)
             D.copy_(torch.from_numpy(d_np))
             I.copy_(torch.from_numpy(i_np))
+        if len(self.segments) > 1:
+            I.copy_(self._to_global(I))
         if self.world == 1:
             return D, I
-        Dg = torch.empty((self.world, nq, k), dtype=torch.float32, device=q.device)
-        Ig = torch.empty((self.world, nq, k), dtype=torch.int64, device=q.device)
-        # the single exchange step of the path: per-shard top-k, 12 bytes per (query, slot)
-        # (concatenated [world*nq, k] view: the only output form every backend accepts)
-        self.dist.all_gather_into_tensor(Dg.view(self.world * nq, k), D, group=self.group)
-        self.dist.all_gather_into_tensor(Ig.view(self.world * nq, k), I, group=self.group)
-        return self._merge(Dg, Ig, k)
+        # THE exchange step of the path: one all-gather of nq*k*12 bytes per rank
+        recv_flat = torch.empty(self.world * record, dtype=torch.uint8, device=q.device)
+        if q.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal of the N > 1 path on a box without RCCL peers: gloo moves host memory
+            host = torch.empty(self.world * record, dtype=torch.uint8)
+            self.dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            recv_flat.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(recv_flat, send, group=self.group)
+        recv = recv_flat.view(self.world, record)
+        if self._merge is None and q.is_cuda:
+            return self._merge_packed_hip(recv, nq, k, record)
+        Ig = recv[:, :ib].view(torch.int64).view(self.world, nq, k)
+        Dg = recv[:, ib:db].view(torch.float32).view(self.world, nq, k)
+        return self._merge(Dg.contiguous(), Ig.contiguous(), k)
 
     def search(self, q: np.ndarray, k: int, normalize: bool = False):
         import torch

@@ -81,6 +81,9 @@ int css_index_ntotal(const css_index* ix, int64_t* n);
 int css_index_dim(const css_index* ix, int* dim);
 int css_index_metric(const css_index* ix, int* metric);
 int css_index_device(const css_index* ix, int* device);
+/* Diagnostics: how many queries of the LAST candidate-path search (its last chunk of up to 4096 queries) overflowed
+ * their candidate buffer or band and were re-run by the exact fix-up.  Waits for the device. */
+int css_index_last_flagged(css_index* ix, int64_t* n);
 /* bf16 shadow rows (the operand of the candidate scans; +50 % HBM next to the fp32 rows): -1 = keep them
  * while fp32 + bf16 rows fit in 80 % of the HBM (default), 0 = never, 1 = always.  Only on an empty index.
  * Results do not depend on it: without shadow rows batches form their candidate scores from the fp32 rows. */
@@ -141,6 +144,12 @@ int css_index_search_masked_dev(css_index* ix, const float* q_dev, int64_t nq, i
 int css_merge_topk_dev(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts,
                        int64_t nq, int k, int metric, float* D_out_dev, int64_t* I_out_dev,
                        int device, void* stream);
+
+/* The same merge straight from the exchange buffer of the sharded search: `nparts` records of `record_bytes`
+ * bytes (a multiple of 8, >= 12 * nq * k), each [nq * k int64 ids][nq * k float scores] -- the layout one
+ * RCCL all-gather of nq * k * 12 bytes per rank produces (a single exchange step). */
+int css_merge_topk_packed_dev(const void* packed_dev, int nparts, int64_t record_bytes, int64_t nq, int k,
+                              int metric, float* D_out_dev, int64_t* I_out_dev, int device, void* stream);
 
 /* ---- MPNet sentence encoder (all-mpnet-base-v2 architecture) ---- */
 typedef struct css_encoder_cfg {

@@ -172,6 +172,39 @@ void knn_oracle_merge(const float* Dp, const int64_t* Ip, int nparts, int64_t nq
     }
 }
 
+/* Heap phase of faiss-cpu's batched search (nq >= 20: blocked SGEMM, then every score of the block is offered to
+ * the query's result heap): S[nq, nb] holds the scores of rows [r0, r0 + nb) -- inner products, or squared
+ * distances for L2 -- and is folded into the running lists D/I[nq, k] (sorted, best first; the caller starts them
+ * at pad / -1).  One thread per query, the common case (score no better than the current k-th) is one compare. */
+void knn_oracle_fold_block(const float* S, int64_t nq, int64_t nb, int64_t r0, int k, int metric, float* D,
+                           int64_t* I) {
+#pragma omp parallel for schedule(static)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const float* s = S + qi * nb;
+        float* Dq = D + qi * (int64_t)k;
+        int64_t* Iq = I + qi * (int64_t)k;
+        int cnt = 0;
+        while (cnt < k && Iq[cnt] >= 0) ++cnt;
+        for (int64_t j = 0; j < nb; ++j) {
+            const float v = s[j];
+            if (cnt == k) {
+                const float kth = Dq[k - 1];
+                if (metric == ORACLE_METRIC_IP ? (v < kth) : (v > kth)) continue;
+                if (!better(metric, v, r0 + j, kth, Iq[k - 1])) continue;
+            }
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0 && better(metric, v, r0 + j, Dq[pos - 1], Iq[pos - 1])) {
+                Dq[pos] = Dq[pos - 1];
+                Iq[pos] = Iq[pos - 1];
+                --pos;
+            }
+            Dq[pos] = v;
+            Iq[pos] = r0 + j;
+            if (cnt < k) ++cnt;
+        }
+    }
+}
+
 int knn_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -59,6 +59,9 @@ def _lib():
     lib.knn_oracle_merge.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                      ctypes.c_int, f32p, i64p]
     lib.knn_oracle_merge.restype = None
+    lib.knn_oracle_fold_block.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int, f32p, i64p]
+    lib.knn_oracle_fold_block.restype = None
     lib.knn_oracle_num_threads.restype = ctypes.c_int
     lib.knn_oracle_set_threads.argtypes = [ctypes.c_int]
     lib.knn_oracle_synth_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64]
@@ -154,38 +157,63 @@ def merge_topk(D_parts: np.ndarray, I_parts: np.ndarray, metric: int = METRIC_IP
     return D, I
 
 
-def search_blas(xb: np.ndarray, q: np.ndarray, k: int, metric: int = METRIC_IP, block: int = 65536):
-    """faiss-cpu's batched path (nq >= 20): blocked SGEMM + per-query heap merge,
-    restated with numpy (BLAS threads = all cores).  Used by bench.py as the
-    ``cpu_baseline`` of kind "port" for query batches."""
+def search_blas(xb: np.ndarray, q: np.ndarray, k: int, metric: int = METRIC_IP, block: int = 16384):
+    """faiss-cpu's batched path (nq >= 20): blocked SGEMM, then every score of the block is offered to the
+    query's result heap.  The SGEMM is numpy's (the BLAS numpy links, all cores); the heap phase is
+    ``knn_oracle_fold_block`` (OpenMP over queries, one compare per score in the common case).  Used by
+    bench.py as the ``cpu_baseline`` of kind "port" for query batches."""
     xb = np.ascontiguousarray(xb, dtype=np.float32)
     q = np.ascontiguousarray(q, dtype=np.float32)
     nq = q.shape[0]
     n = xb.shape[0]
-    best_s = np.full((nq, 0), 0, dtype=np.float32)
-    best_i = np.zeros((nq, 0), dtype=np.int64)
+    D = np.full((nq, k), -np.finfo(np.float32).max if metric == METRIC_IP else np.finfo(np.float32).max, np.float32)
+    I = np.full((nq, k), -1, np.int64)
     qn = (q * q).sum(1)[:, None] if metric == METRIC_L2 else None
+    lib = _lib()
     for r0 in range(0, n, block):
         blk = xb[r0:r0 + block]
         s = q @ blk.T
         if metric == METRIC_L2:
             s = qn + (blk * blk).sum(1)[None, :] - 2.0 * s
             np.maximum(s, 0, out=s)
-            key = s
-        else:
-            key = -s
-        kk = min(k, blk.shape[0])
-        part = np.argpartition(key, kk - 1, axis=1)[:, :kk]
-        ps = np.take_along_axis(s, part, axis=1)
-        cand_s = np.concatenate([best_s, ps], axis=1)
-        cand_i = np.concatenate([best_i, part.astype(np.int64) + r0], axis=1)
-        ck = -cand_s if metric == METRIC_IP else cand_s
-        order = np.lexsort((cand_i, ck), axis=1)[:, :k]
-        best_s = np.take_along_axis(cand_s, order, axis=1)
-        best_i = np.take_along_axis(cand_i, order, axis=1)
-    if best_s.shape[1] < k:
-        pad = k - best_s.shape[1]
-        fill = -np.finfo(np.float32).max if metric == METRIC_IP else np.finfo(np.float32).max
-        best_s = np.concatenate([best_s, np.full((nq, pad), fill, np.float32)], axis=1)
-        best_i = np.concatenate([best_i, np.full((nq, pad), -1, np.int64)], axis=1)
-    return best_s.astype(np.float32), best_i
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        lib.knn_oracle_fold_block(_f32(s), nq, blk.shape[0], r0, int(k), metric, _f32(D), _i64(I))
+    return D, I
+
+
+def search_synth_chunked(n_total: int, d: int, seed: int, q: np.ndarray, k: int, metric: int = METRIC_IP,
+                         normalize: bool = True, chunk: int = 1_000_000, first_row: int = 0):
+    """Exact top-k over a SYNTHETIC index too large to hold: rows ``first_row .. first_row + n_total`` of the
+    ``css_synth.h`` generator are regenerated ``chunk`` rows at a time (optionally row-normalised as
+    ``add_chunks`` does), searched with the plain C sweep, and the per-chunk lists merged with
+    ``knn_oracle_merge``.  Returns ``(D, I, D64)`` with global ids and the fp64 scores of the returned rows."""
+    q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, d)
+    nq = q.shape[0]
+    Dp, Ip, D64p = [], [], []
+    lib = _lib()
+    for r0 in range(0, n_total, chunk):
+        m = min(chunk, n_total - r0)
+        x = synth_rows(m, d, seed, first_row=first_row + r0)
+        if normalize:
+            lib.knn_oracle_normalize_rows(_f32(x), m, d)
+        ref = FlatIndexOracle(d, metric)
+        ref._xb = x
+        kk = min(k, m)
+        Dc, Ic = ref.search(q, kk)
+        D64c = ref.rescore64(q, Ic)
+        if kk < k:
+            padv = -np.finfo(np.float32).max if metric == METRIC_IP else np.finfo(np.float32).max
+            Dc = np.concatenate([Dc, np.full((nq, k - kk), padv, np.float32)], axis=1)
+            Ic = np.concatenate([Ic, np.full((nq, k - kk), -1, np.int64)], axis=1)
+            D64c = np.concatenate([D64c, np.full((nq, k - kk), float(padv))], axis=1)
+        Dp.append(Dc)
+        Ip.append(np.where(Ic >= 0, Ic + r0, -1))
+        D64p.append(D64c)
+        del ref, x
+    Dp, Ip, D64p = np.stack(Dp), np.stack(Ip), np.stack(D64p)
+    D, I = merge_topk(Dp, Ip, metric)
+    D64 = np.empty(I.shape, dtype=np.float64)
+    for r in range(nq):
+        lut = {int(i): float(v) for i, v in zip(Ip[:, r].ravel(), D64p[:, r].ravel()) if i >= 0}
+        D64[r] = [lut.get(int(i), np.nan) for i in I[r]]
+    return D, I, D64

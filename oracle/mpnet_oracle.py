@@ -167,6 +167,51 @@ def encode(w: Dict[str, torch.Tensor], cfg: MpnetCfg, batch: List[Sequence[int]]
     return np.stack(out).astype(np.float32)
 
 
+def encode_batched(w: Dict[str, torch.Tensor], cfg: MpnetCfg, batch: List[Sequence[int]], batch_size: int = 16,
+                   normalize: bool = True) -> np.ndarray:
+    """The same model evaluated the way sentence-transformers runs it on a CPU: ``batch_size`` sequences at a
+    time, padded to the longest of the batch, with the padded-key mask (modeling_mpnet.py: -inf on padded keys),
+    batched matmuls on all torch threads.  Numerically the padded form of ``encode`` (tests/test_oracle_mpnet.py
+    holds the two together); bench.py times this one as the encoder's CPU baseline."""
+    H, nh = cfg.hidden, cfg.heads
+    hd = H // nh
+    out = []
+    with torch.no_grad():
+        for b0 in range(0, len(batch), batch_size):
+            part = batch[b0:b0 + batch_size]
+            B, L = len(part), max(len(s) for s in part)
+            ids = torch.full((B, L), cfg.pad_id, dtype=torch.long)
+            for i, sq in enumerate(part):
+                ids[i, :len(sq)] = torch.tensor(list(sq), dtype=torch.long)
+            mask = (ids != cfg.pad_id).long()
+            pos = torch.cumsum(mask, 1) * mask + cfg.pad_id
+            x = w["embeddings.word_embeddings.weight"][ids] + w["embeddings.position_embeddings.weight"][pos]
+            x = F.layer_norm(x, (H,), w["embeddings.LayerNorm.weight"], w["embeddings.LayerNorm.bias"], cfg.ln_eps)
+            ar = torch.arange(L)
+            bias = w["encoder.relative_attention_bias.weight"][relative_position_bucket(ar[None, :] - ar[:, None],
+                                                                                        cfg.rel_buckets)].permute(2, 0, 1)
+            keymask = torch.zeros((B, 1, 1, L))
+            keymask.masked_fill_(mask[:, None, None, :] == 0, torch.finfo(torch.float32).min)
+            for i in range(cfg.num_layers):
+                p = f"encoder.layer.{i}."
+                lin = lambda t, nm: t @ w[p + nm + ".weight"].T + w[p + nm + ".bias"]  # noqa: E731
+                q = lin(x, "attention.attn.q").view(B, L, nh, hd).transpose(1, 2)
+                k = lin(x, "attention.attn.k").view(B, L, nh, hd).transpose(1, 2)
+                v = lin(x, "attention.attn.v").view(B, L, nh, hd).transpose(1, 2)
+                sc = q @ k.transpose(2, 3) / math.sqrt(hd) + bias[None] + keymask
+                c = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
+                a = F.layer_norm(lin(c, "attention.attn.o") + x, (H,), w[p + "attention.LayerNorm.weight"],
+                                 w[p + "attention.LayerNorm.bias"], cfg.ln_eps)
+                y = lin(F.gelu(lin(a, "intermediate.dense")), "output.dense")
+                x = F.layer_norm(y + a, (H,), w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], cfg.ln_eps)
+            m = mask[:, :, None].float()
+            e = (x * m).sum(1) / m.sum(1).clamp(min=1e-9)
+            if normalize:
+                e = F.normalize(e, p=2, dim=1, eps=1e-12)
+            out.append(e.numpy())
+    return np.concatenate(out).astype(np.float32)
+
+
 def synth_batch(cfg: MpnetCfg, lengths: Sequence[int], seed: int) -> List[List[int]]:
     """Token ids: <s>=0 first, </s>=2 last, uniform in [4, vocab) between."""
     batch = []

@@ -131,17 +131,147 @@ def test_committed_goldens_2layer_and_probes():
 
 
 def test_committed_goldens_12layer():
+    """12 layers, lengths up to the truncation limit, against embeddings computed by transformers.MPNetModel
+    (tests/golden/make_encoder_goldens.py), in both compute modes."""
     from pathlib import Path
 
     from oracle import mpnet_oracle as mo
 
     g = np.load(Path(__file__).resolve().parent / "golden" / "encoder_12layer.npz")
+    assert "transformers" in str(g["source"])
     cfg = mo.MpnetCfg()
     batch = mo.synth_batch(cfg, g["lengths"].tolist(), seed=int(g["bseed"]))
-    enc = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute="bf16")
+    for mode, tol in (("bf16", None), ("fp32", 3e-4)):
+        enc = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute=mode)
+        out = enc.encode_ids(batch)
+        cos = (out * g["emb"]).sum(1)
+        assert cos.min() > 1 - 1e-3, (mode, cos)
+        if tol:
+            assert np.abs(out - g["emb"]).max() < tol, (mode, np.abs(out - g["emb"]).max())
+        enc.close()
+
+
+def test_batch_256x384_product_shape_against_the_oracle():
+    """BASELINE configs[2] at full size: 256 sequences of 384 tokens, 12 layers, bf16 -- the inputs bench.py
+    encodes (token seed 7, weights seed 1).  The persistent GEMM walks 384 row tiles, attention runs 256 x 3 x 12
+    blocks, pooling reduces 98 304 token rows: 16 sequences spread over the batch (first, last, tile boundaries)
+    are checked against the CPU oracle, and the same sequences encoded alone must give the same embeddings."""
+    import torch
+
+    from claude_semantic_search_amd import synth
+    from oracle import mpnet_oracle as mo
+
+    B, L = 256, 384
+    cfg = mo.MpnetCfg()
+    ids = synth.uint(7, np.arange(B * L, dtype=np.uint64), 4, cfg.vocab).astype(np.int32)
+    ids[0::L] = 0
+    ids[L - 1::L] = 2
+    batch = [ids[i * L:(i + 1) * L].tolist() for i in range(B)]
+    enc = MpnetEncoder(synthetic_seed=1, compute="bf16")
     out = enc.encode_ids(batch)
-    cos = (out * g["emb"]).sum(1)
+    assert out.shape == (B, 768) and np.isfinite(out).all()
+    assert np.abs(np.linalg.norm(out, axis=1) - 1.0).max() < 1e-4
+    pick = [0, 1, 2, 17, 63, 64, 100, 127, 128, 170, 191, 192, 230, 253, 254, 255]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = mo.encode(mo.synth_weights(cfg, 1), cfg, [batch[i] for i in pick])
+    cos = (out[pick] * ref).sum(1)
     assert cos.min() > 1 - 1e-3, cos
+    assert np.abs(out[pick] - ref).max() < 2e-2
+    # batch composition must not matter: the same rows through a 16-sequence batch (other tile walk, same kernels)
+    # and one sequence alone (the 128x128-tile GEMM configuration: another summation order, bf16 rounding noise only)
+    small = enc.encode_ids([batch[i] for i in pick])
+    assert ((small * out[pick]).sum(1)).min() > 1 - 1e-5 and np.abs(small - out[pick]).max() < 5e-3
+    alone = enc.encode_ids([batch[255]])
+    assert float((alone[0] * out[255]).sum()) > 1 - 1e-5
+    # different sequences give different embeddings (a stuck tile would repeat rows)
+    assert len({tuple(np.round(r[:8], 4)) for r in out}) == B
+    enc.close()
+
+
+def _write_checkpoint(dirpath, cfg, w, prefix="", with_pooler=True, subdir=False):
+    """A local model directory in the layout sentence-transformers / transformers write: config.json +
+    model.safetensors with the HF key names (q / k / v unfused), optionally under 0_Transformer/."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    root = dirpath / "0_Transformer" if subdir else dirpath
+    root.mkdir(parents=True, exist_ok=True)
+    (root / "config.json").write_text(json.dumps({
+        "model_type": "mpnet", "num_hidden_layers": cfg.num_layers, "hidden_size": cfg.hidden,
+        "num_attention_heads": cfg.heads, "intermediate_size": cfg.ffn, "vocab_size": cfg.vocab,
+        "max_position_embeddings": cfg.max_pos, "relative_attention_num_buckets": cfg.rel_buckets,
+        "pad_token_id": cfg.pad_id, "layer_norm_eps": cfg.ln_eps}))
+    sd = {prefix + k: v.numpy() for k, v in w.items()}
+    if with_pooler:   # present in real checkpoints, unused by sentence-transformers' Pooling(mean)
+        sd[prefix + "pooler.dense.weight"] = np.zeros((cfg.hidden, cfg.hidden), np.float32)
+        sd[prefix + "pooler.dense.bias"] = np.zeros((cfg.hidden,), np.float32)
+        sd[prefix + "embeddings.position_ids"] = np.arange(cfg.max_pos, dtype=np.float32)[None]
+    save_file(sd, str(root / "model.safetensors"))
+    return sd
+
+
+@pytest.mark.parametrize("prefix,subdir", [("", False), ("mpnet.", False), ("0.auto_model.", True)])
+def test_checkpoint_directory_loads_like_the_synthetic_init(tmp_path, prefix, subdir):
+    """The real-weight path (src/embeddings.py:86-88 of the reference: SentenceTransformer(name, cache_folder)):
+    directory discovery, safetensors read, prefix stripping, unfused q/k/v -> fused [2304, 768], pooler skipped.
+    The same seeded tensors written as a checkpoint and loaded through MpnetEncoder(path) must give the device
+    weights and the embeddings of css_encoder_init_synthetic bit for bit, and match the transformers golden."""
+    from pathlib import Path
+
+    from oracle import mpnet_oracle as mo
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "encoder_2layer.npz")
+    cfg = mo.MpnetCfg(num_layers=2)
+    w = mo.synth_weights(cfg, int(g["wseed"]))
+    _write_checkpoint(tmp_path / "all-mpnet-base-v2", cfg, w, prefix=prefix, subdir=subdir)
+    batch = mo.synth_batch(cfg, g["lengths"].tolist(), seed=int(g["bseed"]))
+    for mode, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        # by name + cache_folder, as the reference constructs it
+        enc = MpnetEncoder("all-mpnet-base-v2", cache_folder=str(tmp_path), compute=mode)
+        assert enc.cfg["num_layers"] == 2 and enc.get_sentence_embedding_dimension() == 768
+        syn = MpnetEncoder(synthetic_seed=int(g["wseed"]), compute=mode, cfg_overrides={"num_layers": 2})
+        for name, shape in (("embeddings.word_embeddings.weight", (cfg.vocab, 768)),
+                            ("encoder.layer.1.attention.attn.qkv.weight", (2304, 768)),
+                            ("encoder.layer.0.attention.attn.qkv.bias", (2304,)),
+                            ("encoder.layer.1.attention.attn.v.weight", (768, 768)),
+                            ("encoder.layer.0.output.dense.weight", (768, 3072)),
+                            ("encoder.relative_attention_bias.weight", (32, 12))):
+            assert np.array_equal(enc.export_weight(name, shape), syn.export_weight(name, shape)), name
+        out, ref = enc.encode_ids(batch), syn.encode_ids(batch)
+        assert np.array_equal(out, ref)
+        assert np.abs(out - g["emb"]).max() < tol and ((out * g["emb"]).sum(1)).min() > 1 - 1e-3
+        enc.close()
+        syn.close()
+
+
+def test_incomplete_or_ambiguous_checkpoints_are_rejected(tmp_path):
+    from oracle import mpnet_oracle as mo
+    from claude_semantic_search_amd._native import CssError
+
+    cfg = mo.MpnetCfg(num_layers=1)
+    w = mo.synth_weights(cfg, 2)
+    sd = {k: v.numpy() for k, v in w.items()}
+    enc = MpnetEncoder(synthetic_seed=2, compute="fp32", cfg_overrides={"num_layers": 1})
+    enc.load_state_dict(sd)                                   # complete: accepted
+    for drop in ("encoder.layer.0.attention.attn.k.bias", "encoder.layer.0.output.LayerNorm.weight",
+                 "embeddings.position_embeddings.weight"):
+        part = {k: v for k, v in sd.items() if k != drop}
+        with pytest.raises(CssError, match="cover|no tensor"):
+            enc.load_state_dict(part)
+    dup = dict(sd)
+    dup["mpnet.encoder.layer.0.attention.attn.o.bias"] = sd["encoder.layer.0.attention.attn.o.bias"]
+    with pytest.raises(CssError, match="more than once"):
+        enc.load_state_dict(dup)
+    bad = dict(sd)
+    bad["encoder.layer.0.intermediate.dense.bias"] = np.zeros(7, np.float32)
+    with pytest.raises(CssError, match="elements"):
+        enc.load_state_dict(bad)
+    with pytest.raises(CssError, match="unknown parameter"):
+        enc.load_state_dict({**sd, "encoder.layer.5.output.dense.bias": np.zeros(768, np.float32)})
+    enc.load_state_dict(sd)                                   # still usable afterwards
+    ref = mo.encode(w, cfg, [[0, 9, 77, 2]])
+    assert np.abs(enc.encode_ids([[0, 9, 77, 2]]) - ref).max() < 1e-4
     enc.close()
 
 

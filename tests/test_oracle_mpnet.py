@@ -53,6 +53,37 @@ def test_oracle_matches_transformers_mpnet_padded_batch():
     assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-6)
 
 
+def test_oracle_matches_transformers_12_layers_full_length():
+    """The full 12-layer architecture at the truncation length (384) and one below it: last hidden states and
+    pooled embeddings of the oracle against transformers.MPNetModel on a padded batch with its attention mask."""
+    torch.set_num_threads(8)
+    cfg = mo.MpnetCfg()
+    w = mo.synth_weights(cfg, seed=3)
+    hf = _hf_model(cfg, w)
+    lengths = [384, 383, 129]
+    batch = mo.synth_batch(cfg, lengths, seed=21)
+    ids = torch.full((3, 384), cfg.pad_id, dtype=torch.long)
+    mask = torch.zeros((3, 384), dtype=torch.long)
+    for b, s in enumerate(batch):
+        ids[b, :len(s)] = torch.tensor(s)
+        mask[b, :len(s)] = 1
+    with torch.no_grad():
+        hs = hf(input_ids=ids, attention_mask=mask).last_hidden_state
+        for b, s in enumerate(batch):
+            mine = mo.encode_tokens(w, cfg, s)
+            assert torch.allclose(mine, hs[b, :len(s)], atol=3e-5), float((mine - hs[b, :len(s)]).abs().max())
+    m = mask[:, :, None].float()
+    ref = torch.nn.functional.normalize((hs * m).sum(1) / m.sum(1).clamp(min=1e-9), p=2, dim=1).numpy()
+    assert np.abs(mo.encode(w, cfg, batch) - ref).max() < 2e-6
+
+
+def test_batched_padded_oracle_equals_the_per_sequence_oracle():
+    cfg = mo.MpnetCfg(num_layers=2)
+    w = mo.synth_weights(cfg, seed=9)
+    batch = mo.synth_batch(cfg, [33, 5, 64, 1, 17, 40, 2], seed=3)
+    assert np.abs(mo.encode_batched(w, cfg, batch, batch_size=3) - mo.encode(w, cfg, batch)).max() < 2e-6
+
+
 def test_rel_bucket_table_spot_values_and_library_helper():
     from transformers.models.mpnet import modeling_mpnet as mm
     from claude_semantic_search_amd import _native as nat
@@ -91,4 +122,13 @@ def test_committed_bucket_table_and_goldens_reproduce():
     cfg = mo.MpnetCfg(num_layers=2)
     lengths = g["lengths"].tolist()[:3]  # the short ones keep the CPU suite fast
     out = mo.encode(mo.synth_weights(cfg, int(g["wseed"])), cfg, mo.synth_batch(cfg, g["lengths"].tolist(), seed=int(g["bseed"]))[:3])
+    # the committed embeddings come from transformers.MPNetModel (make_encoder_goldens.py), not from the oracle
+    assert "transformers" in str(g["source"]) and float(g["oracle_maxdiff"]) < 2e-6
     assert np.abs(out - g["emb"][:3]).max() < 2e-6
+    g12 = np.load(gold / "encoder_12layer.npz")
+    assert "transformers" in str(g12["source"]) and float(g12["oracle_maxdiff"]) < 2e-6
+    cfg12 = mo.MpnetCfg()
+    b12 = mo.synth_batch(cfg12, g12["lengths"].tolist(), seed=int(g12["bseed"]))
+    pick = [0, 4, 6]  # the short ones (8, 17 and 1 tokens) keep the CPU suite fast
+    out12 = mo.encode(mo.synth_weights(cfg12, int(g12["wseed"])), cfg12, [b12[i] for i in pick])
+    assert np.abs(out12 - g12["emb"][pick]).max() < 2e-6

@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the multi-GPU search skeleton (row partition ->
-local top-k -> one all-gather -> merge) equals one big index.  Device pieces are
+local top-k -> one packed all-gather -> merge) equals one big index, also after several adds of every kind.  Device pieces are
 replaced by oracle-backed doubles defined here; the product wiring is covered on
 the GPU by tests/test_knn_gpu.py::test_id_base_and_merge_parts_match_whole."""
 import os
@@ -66,6 +66,54 @@ def _worker(rank, world, port, metric, out_dir):
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), D=D, I=I)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_incremental(rank, world, port, out_dir):
+    """Several adds of each kind: global ids must be those of ONE index that received the same calls in order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from claude_semantic_search_amd import synth
+        from claude_semantic_search_amd.sharded import ShardedFlatIndex
+
+        d, k = 64, 10
+        sh = ShardedFlatIndex(d, 0, index_factory=lambda: _FakeLocal(d, 0), merge=_merge(0))
+        sh.add_global(synth.rows(10, d, 31), normalize=True)          # rows 0..9:   5 + 5
+        sh.add_global(synth.rows(10, d, 32), normalize=True)          # rows 10..19: 5 + 5 (second segment per shard)
+        t1 = sh.add_routed(synth.rows(7, d, 33), normalize=True)      # rows 20..26 -> rank 0 (tie: lowest rank)
+        t2 = sh.add_routed(synth.rows(3, d, 34), normalize=True)      # rows 27..29 -> rank 1 (least full)
+        sh.add_synthetic_global(401, seed=35, normalize=True)         # rows 30..430
+        t3 = sh.add_routed(synth.rows(2, d, 36), normalize=True)      # rows 431..432
+        assert (t1, t2) == (0, 1) and t3 in (0, 1)
+        assert sh.ntotal_global == 433 and sum(sh.shard_sizes) == 433 and sh.local.ntotal == sh.shard_sizes[rank]
+        assert len(sh.segments) >= 3
+        q = synth.rows(21, d, 37)
+        D, I = sh.search(q, k, normalize=True)
+        np.savez(os.path.join(out_dir, f"inc{rank}.npz"), D=D, I=I)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_incremental_adds_number_rows_like_one_index(tmp_path):
+    from oracle import knn_oracle as ko
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_incremental, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d, k = 64, 10
+    parts = [ko.synth_rows(10, d, 31), ko.synth_rows(10, d, 32), ko.synth_rows(7, d, 33), ko.synth_rows(3, d, 34),
+             ko.synth_rows(401, d, 35), ko.synth_rows(2, d, 36)]
+    ref = ko.FlatIndexOracle(d, 0)
+    ref.add(ko.normalize_rows(np.concatenate(parts)))
+    Dr, Ir = ref.search(ko.normalize_rows(ko.synth_rows(21, d, 37)), k)
+    for r in range(2):
+        got = np.load(tmp_path / f"inc{r}.npz")
+        assert np.array_equal(got["I"], Ir), f"rank {r}"
+        assert np.array_equal(got["D"], Dr), f"rank {r}"
+        assert len(set(got["I"].ravel().tolist())) > k     # (ids are not all from one shard)
 
 
 @pytest.mark.parametrize("metric", [0, 1])

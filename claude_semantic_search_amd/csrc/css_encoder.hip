@@ -272,6 +272,7 @@ int g_enc_resid = 2;       // CSS_ENC_RESID: residual stream storage in bf16 mod
 int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
 int g_gemm_big_tiles = 1;
 int g_gemm_mfma16 = 1;     // CSS_GEMM_MFMA=32: 32x32x16 MFMA kernel (k_gemm) instead of k_gemm16
+int g_gemm_8phase = 1;     // CSS_GEMM_LOOP=old: the round-1 main loop (k_gemm16) instead of k_gemm8p, for A/B runs
 // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
 
 template <typename TIn, int EPI>
@@ -291,6 +292,24 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M,
     if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
         // ring: 2 stages x 128 B rows.  Rings of 3 / 4 x 64 B rows and 5 x 64 B with two stages per step were
         // measured slower (more barriers, same LDS fill rate) and are not kept.
+        if constexpr (sizeof(TIn) == 2 && (EPI == EPI_QKV || EPI == EPI_GELU)) {
+            if (g_gemm_8phase && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32)) {
+                auto kern = k_gemm8p<EPI>;
+                constexpr size_t lds = 2 * 4 * G8_HT;
+                int dev_ = 0;
+                (void)hipGetDevice(&dev_);
+                int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);
+                if (rc_ != CSS_OK) return rc_;
+                const int ntiles = (N / 256) * ((M + 255) / 256);
+                int grid = std::min(ntiles, num_cus);
+                grid = std::max(8, grid / 8 * 8);
+                ProfScope ps(prof, st);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N,
+                                   K, qscale_cols, qscale);
+                CSS_LAUNCH_CHECK();
+                return CSS_OK;
+            }
+        }
         if constexpr (sizeof(TIn) == 2) {
             if (g_gemm_mfma16) {  // product mode: the 16x16x32 MFMA variant (CSS_GEMM_MFMA=32 selects k_gemm for A/B runs)
                 CSS_REQUIRE(K % 64 == 0 && K / 64 >= 3, "gemm: K=%d must be a multiple of 64 (>= 192)", K);
@@ -432,6 +451,7 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
     if (const char* t = getenv("CSS_ENC_RESID")) g_enc_resid = atoi(t);
     if (const char* t = getenv("CSS_GEMM_MFMA")) g_gemm_mfma16 = atoi(t) != 32;
+    if (const char* t = getenv("CSS_GEMM_LOOP")) g_gemm_8phase = std::string(t) != "old";
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;

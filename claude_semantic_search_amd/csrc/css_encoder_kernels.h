@@ -203,6 +203,41 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// GELU without transcendentals (the product GEMM's epilogue is VALU bound: v_rcp / v_exp issue at a quarter of the
+// plain rate and were 40 % of gelu_erf_fast's cycles).  gelu(x) = relu(x) - g(|x|) with g(a) = a Phi(-a), a smooth
+// bump that is 1.5e-5 at a = 4.5 and falls from there; g is a degree-10 minimax-style polynomial (Chebyshev fit,
+// monomials in t = 2a/4.5 - 1) on [0, 4.5], clamped beyond.  |error| <= 1.7e-5 absolute against erf GELU in fp32
+// Horner form (checked over [-8, 8] in 8e-6 steps): below a bf16 half ulp for every |gelu(x)| > 8e-3, and the
+// result is rounded to bf16 right after.
+// Four elements at once so that the four Horner chains interleave (one chain alone is a string of dependent FMAs);
+// |x| clamp and relu on the raw bits (v_and / v_min_u32 / v_max_i32: the float min / max forms carry an extra
+// canonicalising v_max each under IEEE mode).
+__device__ __forceinline__ v4f gelu_poly4(v4f x) {
+    v4f t, p, r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned ab = min(__float_as_uint(x[e]) & 0x7FFFFFFFu, 0x40900000u);   // min(|x|, 4.5) (non-negative floats order like their bits)
+        t[e] = fmaf(__uint_as_float(ab), 0.44444444444f, -1.0f);
+        r[e] = __int_as_float(max(__float_as_int(x[e]), 0));                          // relu(x); -0.0 and NaN payloads aside
+        p[e] = -4.423601382e-02f;
+    }
+#define CSS_GP_STEP(C_) _Pragma("unroll") for (int e = 0; e < 4; ++e) p[e] = fmaf(p[e], t[e], C_);
+    CSS_GP_STEP(2.258405084e-02f)
+    CSS_GP_STEP(1.802777630e-01f)
+    CSS_GP_STEP(-1.780532284e-01f)
+    CSS_GP_STEP(-2.080824415e-01f)
+    CSS_GP_STEP(4.360252249e-01f)
+    CSS_GP_STEP(-2.019351235e-01f)
+    CSS_GP_STEP(-1.475407927e-01f)
+    CSS_GP_STEP(2.464785522e-01f)
+    CSS_GP_STEP(-1.330170564e-01f)
+    CSS_GP_STEP(2.749903583e-02f)
+#undef CSS_GP_STEP
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] -= p[e];
+    return r;
+}
+
 // TIn: operand type (bf16_t or float).  Output: EPI_RESID -> fp32 [M,N] = acc + bias (the
 // residual is added by k_layernorm); EPI_QKV / EPI_GELU -> TIn [M,N]; EPI_QKV scales columns
 // < qscale_cols by 0.125 (1/sqrt(64)).
@@ -637,6 +672,279 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
         }
     }
 #undef G16_ISSUE
+}
+
+// ---------------------------------------------------------------- bf16 GEMM, 8-phase ping-pong main loop
+// The product-mode GEMM of the encoder (same contract as k_gemm16: C[M,N] bf16 = A[M,K] . W[N,K]^T + bias, then the
+// EPI transform; 256 x 256 tiles, persistent, XCD-aware tile walk) with the main loop restructured after the
+// "256^2 8-phase template" of cdna_hip_programming.md:
+//
+//   * a 64-deep K step is four PHASES of 16 MFMAs (one quadrant of the wave's 128 x 64 output each); every phase is
+//     [fragment reads + 2 LDS-DMA instructions]  s_barrier  [16 MFMAs]  s_barrier;
+//   * wave row 1 (waves 4..7) runs ONE barrier behind wave row 0, so on every SIMD one wave issues MFMAs while its
+//     partner reads fragments and issues DMA (MI355X_MICROARCH.md, "Two waves per SIMD", item 9);
+//   * LDS = 2 K-step buffers x 4 half-tile slots of 16 KiB, in issue order A0, B0, B1, A1:
+//         A_s: rows {wr*128 + s*64 + [0,64)}, slot row wr*64 + r   (a wave row reads and refills only its own 64 rows)
+//         B_s: rows {wc*64 + s*32 + [0,32)},  slot row wc*32 + r
+//     K step u (buffer D = u & 1):  P1 reads A_0, B_0   issues A_1(u+1) -> D^1      MFMA (A0, B0)
+//                                   P2 reads B_1        issues A_0(u+2) -> D        MFMA (A0, B1)
+//                                   P3 reads A_1        issues B_0(u+2) -> D        MFMA (A1, B1)
+//                                   P4 (B_0 in regs)    issues B_1(u+2) -> D        MFMA (A1, B0)
+//     so three half tiles stay in flight behind a counted vmcnt(6) at P4 (K step u+1 has landed; its first reads
+//     come two barriers later).  A slot is refilled one phase after its last read when only the refilling wave
+//     row reads it (A), two phases after when both wave rows read it (B): with the one-barrier stagger every read
+//     has been waited for (lgkmcnt(0) right behind the phase's first barrier) before the refill is issued;
+//   * accumulators START from the bias row (DMA'd into LDS one tile ahead, read with inline-asm ds_read: a
+//     compiler-visible LDS read beside pending LDS-DMA makes hipcc drain the queue with vmcnt(0)); the epilogue is
+//     EPI transform -> bf16 -> per-wave 16 x 64 LDS transpose (inline asm, same reason) -> 16-B nontemporal stores
+//     of full 128-B lines.
+// Measured on MI355X (tools/gemm_lab.hip, same data, one process): 98304 x 2304 x 768: 0.300 vs 0.360 ms for
+// k_gemm16; x 768 x 768: 0.107 vs 0.134; x 768 x 3072: 0.361 vs 0.457.  Requires K % 128 == 0, N % 256 == 0,
+// M * K * 2 < 4 GiB (32-bit source offsets) and >= 256 slack rows behind A and C.
+constexpr int G8_HT = 16384;
+constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
+                                                int K, int qscale_cols, float qscale) {
+    static_assert(EPI == EPI_QKV || EPI == EPI_GELU, "bf16 output epilogues");
+    constexpr int NW = 8, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][G8_HT]
+    __shared__ __attribute__((aligned(16))) float sbias[2][BN];
+    constexpr int EPI_ROW = 144;
+    __shared__ __attribute__((aligned(16))) char sepi[NW][16 * EPI_ROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lq = lane & 15, lg = lane >> 4;
+
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
+    const int KT = K / 64;                 // even (host check)
+    const int total = my_ntiles * KT;      // K steps of this block
+    if (total == 0) return;
+
+    // ---- DMA bookkeeping: one 32-bit source offset per half-tile kind (its first 1-KiB piece; the second piece is 8
+    // rows further and its swizzled chunk differs by XOR 4), advanced independently.  Rows beyond M read the slack
+    // rows of the activation buffer (their outputs land in slack rows too).
+    const int prow = lane >> 3, pchunk = lane & 7;
+    unsigned srco[4];
+    int it_tile[4], it_kt[4];
+    int dsto[4];  // byte offset of this wave's first piece inside a slot
+    dsto[G8_A0] = dsto[G8_A1] = (wr * 64 + wc * 16) * 128;
+    dsto[G8_B0] = dsto[G8_B1] = (16 * wave) * 128;
+    const unsigned row8 = 8u * (unsigned)K * 2u;
+#define G8_SET_SRC(KIND_)                                                                                     \
+    {                                                                                                         \
+        const int tile_ = xfirst + jx + it_tile[KIND_] * per_x;                                               \
+        const int r0_ = (tile_ / ntn) * BM, c0_ = (tile_ % ntn) * BN;                                         \
+        int srow_, grow_;                                                                                     \
+        if ((KIND_) == G8_A0 || (KIND_) == G8_A1) {                                                           \
+            const int rr_ = wc * 16 + prow;                                                                   \
+            srow_ = wr * 64 + rr_;                                                                            \
+            grow_ = r0_ + wr * 128 + ((KIND_) == G8_A1 ? 64 : 0) + rr_;                                       \
+        } else {                                                                                              \
+            srow_ = 16 * wave + prow;                                                                         \
+            grow_ = c0_ + (srow_ >> 5) * 64 + ((KIND_) == G8_B1 ? 32 : 0) + (srow_ & 31);                     \
+        }                                                                                                     \
+        srco[KIND_] = (unsigned)grow_ * (unsigned)K * 2u + ((pchunk ^ ((srow_ >> 1) & 7)) << 4);              \
+    }
+// issue kind KIND_ of its next K step into buffer DB_, then advance that kind's cursor (past the block's last K
+// step the cursor keeps re-reading the last tile: harmless -- the slot it lands in is never read again -- and it
+// keeps the issue free of branches)
+#define G8_ISSUE(KIND_, DB_)                                                                                  \
+    {                                                                                                         \
+        const char* base_ = reinterpret_cast<const char*>(((KIND_) == G8_A0 || (KIND_) == G8_A1) ? A : W);    \
+        const unsigned o0_ = srco[KIND_] + (unsigned)it_kt[KIND_] * 128u;                                     \
+        const unsigned o1_ = (o0_ + row8) ^ 64u;                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o0_),        \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * G8_HT + dsto[KIND_]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o1_),        \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * G8_HT + dsto[KIND_] + 1024), 16, 0, 0); \
+        if (++it_kt[KIND_] == KT) {                                                                           \
+            it_kt[KIND_] = 0;                                                                                 \
+            if (it_tile[KIND_] + 1 < my_ntiles) {                                                             \
+                ++it_tile[KIND_];                                                                             \
+                G8_SET_SRC(KIND_)                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+// bias row of tile TI_ -> sbias[TI_ & 1]: 1 KiB = one DMA instruction of wave 0
+#define G8_BIAS(TI_)                                                                                          \
+    if (wave == 0) {                                                                                          \
+        const int tile_b = xfirst + jx + (TI_) * per_x;                                                       \
+        __builtin_amdgcn_global_load_lds(                                                                     \
+            (const __attribute__((address_space(1))) void*)(bias + (tile_b % ntn) * BN + 4 * lane),           \
+            (__attribute__((address_space(3))) void*)(&sbias[(TI_) & 1][0]), 16, 0, 0);                        \
+    }
+// accumulators := bias row PAR_ (inline-asm LDS reads, see the header comment)
+#define G8_ACC_FROM_BIAS(PAR_)                                                                                \
+    {                                                                                                         \
+        v4f bv_[4];                                                                                           \
+        const unsigned sboff_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[PAR_][wc * 64 + 4 * lg]; \
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t" \
+                     "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"                                 \
+                     : "=&v"(bv_[0]), "=&v"(bv_[1]), "=&v"(bv_[2]), "=&v"(bv_[3]) : "v"(sboff_) : "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                         \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[m][n] = bv_[n];                                 \
+    }
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+        it_tile[kd] = 0;
+        it_kt[kd] = 0;
+    }
+    G8_SET_SRC(G8_A0)
+    G8_SET_SRC(G8_B0)
+    G8_SET_SRC(G8_B1)
+    G8_SET_SRC(G8_A1)
+
+    v4f acc[8][4];
+    // ---- prologue: K step 0 entirely, K step 1 without its A_1
+    G8_BIAS(0)
+    G8_ISSUE(G8_A0, 0)
+    G8_ISSUE(G8_B0, 0)
+    G8_ISSUE(G8_B1, 0)
+    G8_ISSUE(G8_A1, 0)
+    G8_ISSUE(G8_A0, 1)   // (total >= 2: KT is even)
+    G8_ISSUE(G8_B0, 1)
+    G8_ISSUE(G8_B1, 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    G8_ACC_FROM_BIAS(0)
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+
+    // fragment read offsets (bytes inside a slot): row r + 16 j keeps (r >> 1) & 7, so the rows of the j-th 16-row
+    // tile are 2048 j bytes further; the second 32-wide k step is chunk ^ 4 = byte offset ^ 64
+    const int a_o0 = swz_byte(wr * 64 + lq, lg), a_o1 = a_o0 ^ 64;
+    const int b_o0 = swz_byte(wc * 32 + lq, lg), b_o1 = b_o0 ^ 64;
+    v4f a[4][2], b0[2][2], b1[2][2];
+#define G8_READ_A(S_, D_)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+        a[j][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_A1 : G8_A0)) * G8_HT + j * 2048 + a_o0); \
+        a[j][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_A1 : G8_A0)) * G8_HT + j * 2048 + a_o1); \
+    }
+#define G8_READ_B(S_, D_, B_)                                                                                 \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                           \
+        B_[n][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_B1 : G8_B0)) * G8_HT + n * 2048 + b_o0); \
+        B_[n][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_B1 : G8_B0)) * G8_HT + n * 2048 + b_o1); \
+    }
+// transposed product (MFMA rows <- W rows, columns <- tokens): a lane owns one token row and 4 consecutive columns
+#define G8_MFMA(MH_, NH_, B_)                                                                                 \
+    {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                 \
+                    acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+                        __builtin_bit_cast(v8bf, B_[n][c]), __builtin_bit_cast(v8bf, a[j][c]),                \
+                        acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                          \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
+#define G8_SYNC_A()                                   \
+    __builtin_amdgcn_sched_barrier(0);                \
+    __builtin_amdgcn_s_barrier();                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+#define G8_SYNC_B()                    \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier();      \
+    __builtin_amdgcn_sched_barrier(0);
+    int ct_tile = 0, kt = 0;
+#define G8_KSTEP(D_)                                                                                          \
+    {                                                                                                         \
+        /* P1 */                                                                                              \
+        G8_READ_B(0, D_, b0)                                                                                  \
+        G8_READ_A(0, D_)                                                                                      \
+        G8_ISSUE(G8_A1, (D_) ^ 1)                                                                             \
+        G8_SYNC_A()                                                                                           \
+        G8_MFMA(0, 0, b0)                                                                                     \
+        G8_SYNC_B()                                                                                           \
+        /* P2 */                                                                                              \
+        G8_READ_B(1, D_, b1)                                                                                  \
+        G8_ISSUE(G8_A0, D_)                                                                                   \
+        if (kt == 0 && ct_tile + 1 < my_ntiles) G8_BIAS(ct_tile + 1)                                          \
+        G8_SYNC_A()                                                                                           \
+        G8_MFMA(0, 1, b1)                                                                                     \
+        G8_SYNC_B()                                                                                           \
+        /* P3 */                                                                                              \
+        G8_READ_A(1, D_)                                                                                      \
+        G8_ISSUE(G8_B0, D_)                                                                                   \
+        G8_SYNC_A()                                                                                           \
+        G8_MFMA(1, 1, b1)                                                                                     \
+        G8_SYNC_B()                                                                                           \
+        /* P4 */                                                                                              \
+        G8_ISSUE(G8_B1, D_)                                                                                   \
+        if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                   \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        G8_SYNC_A()                                                                                           \
+        G8_MFMA(1, 0, b0)                                                                                     \
+        G8_SYNC_B()                                                                                           \
+        ++g;                                                                                                  \
+        ++kt;                                                                                                 \
+    }
+
+    for (int g = 0; g < total;) {
+        G8_KSTEP(0)
+        G8_KSTEP(1)
+        if (kt == KT) {
+            // ---- epilogue of output tile ct_tile (no block barrier inside: the stagger carries over)
+            const int tile = xfirst + jx + ct_tile * per_x;
+            const int col0 = (tile % ntn) * BN + wc * 64;
+            const unsigned wbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + lq * EPI_ROW + 8 * lg);
+            const unsigned rbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + (lane >> 3) * EPI_ROW + (lane & 7) * 16);
+            bf16_t* cbase = Cout + (size_t)((tile / ntn) * BM + wr * 128 + (lane >> 3)) * N + col0 + (lane & 7) * 8;
+            float sc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sc[n] = (EPI == EPI_QKV && col0 + 16 * n < qscale_cols) ? qscale : 1.0f;  // qscale_cols % 16 == 0
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                uint2 pk[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    v4f v = acc[m][n];
+                    if constexpr (EPI == EPI_GELU) {
+                        v = gelu_poly4(v);
+                    } else {
+                        v[0] *= sc[n]; v[1] *= sc[n]; v[2] *= sc[n]; v[3] *= sc[n];
+                    }
+                    pk[n].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk[n].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                }
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u o0, o1;
+                asm volatile("ds_write_b64 %6, %2\n\tds_write_b64 %6, %3 offset:32\n\tds_write_b64 %6, %4 offset:64\n\t"
+                             "ds_write_b64 %6, %5 offset:96\n\ts_waitcnt lgkmcnt(0)\n\t"
+                             "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(o0), "=&v"(o1)
+                             : "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(wbase), "v"(rbase), "n"(8 * EPI_ROW)
+                             : "memory");
+                __builtin_nontemporal_store(o0, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m) * N));
+                __builtin_nontemporal_store(o1, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m + 8) * N));
+            }
+            // bias row of the NEXT tile (in LDS since P2 of this tile's first K step) -> accumulator start values
+            G8_ACC_FROM_BIAS((ct_tile + 1) & 1)
+            kt = 0;
+            ++ct_tile;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
+#undef G8_KSTEP
+#undef G8_SYNC_A
+#undef G8_SYNC_B
+#undef G8_MFMA
+#undef G8_READ_A
+#undef G8_READ_B
+#undef G8_ACC_FROM_BIAS
+#undef G8_BIAS
+#undef G8_ISSUE
+#undef G8_SET_SRC
 }
 
 // ---------------------------------------------------------------- skinny GEMM (M <= 64 tokens)

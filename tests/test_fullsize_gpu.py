@@ -107,13 +107,14 @@ def test_1m_clustered_rows_every_mode_matches_the_cpu_oracle():
         ref._xb[c0:c0 + 100_000] = ko.normalize_rows(x)
     q = np.concatenate([cent[:200] + 0.02 * synth.rows(200, D, 90), synth.rows(100, D, 91)])
     qn = ko.normalize_rows(q)
-    Dr, Ir = ko.search_blas(ref._xb, qn, K)
+    Dr, Ir = ko.search_blas(ref._xb, qn, K + 1)     # one rank more: the gap behind the last returned slot
     D64 = ref.rescore64(qn, Ir)
     for nq in (1, 300):
         for mode in ("coarse", "exact_fp32"):
             ix.set_search_mode(mode)
             Da, Ia = ix.search(q[:nq], K, normalize=True)
-            assert_topk_matches(Da, Ia, Dr[:nq], Ir[:nq], D64[:nq], f"1M clustered [{mode}] nq={nq}")
+            assert_topk_matches(Da, Ia, Dr[:nq, :K], Ir[:nq, :K], D64[:nq, :K], f"1M clustered [{mode}] nq={nq}",
+                                D64_next=D64[:nq, K])
     ix.close()
 
 

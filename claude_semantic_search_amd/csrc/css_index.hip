@@ -1156,7 +1156,8 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
     // the shadow can only be carried over (or started on an empty index), never rebuilt here
     const bool can_shadow = ix->xh != nullptr || ix->ntotal == 0;
     if (can_shadow && want_shadow(ix, ncap)) {
-        if (hipMalloc((void**)&nxh, (size_t)ncap * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
+        // (+256 rows: k_scan_coarse8 reads whole 256-row tiles; scores of rows >= ntotal are masked)
+        if (hipMalloc((void**)&nxh, ((size_t)ncap + 256) * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
             (void)hipGetLastError();  // no room: batched search falls back to the split-operand kernel
             nxh = nullptr;
         }
@@ -1190,7 +1191,7 @@ int ensure_capacity(css_index* ix, int64_t need) {
     }
     if (ix->ntotal == 0 && !ix->xh && ix->shadow < 0 && ix->cap > 0 && want_shadow(ix, ix->cap)) {
         // emptied index (css_index_reset): start a shadow again if there is room now
-        if (hipMalloc((void**)&ix->xh, (size_t)ix->cap * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
+        if (hipMalloc((void**)&ix->xh, ((size_t)ix->cap + 256) * ix->dpad * sizeof(unsigned short)) != hipSuccess) {
             (void)hipGetLastError();
             ix->xh = nullptr;
         }
@@ -1223,6 +1224,7 @@ struct KnnEnv {
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
+    int loop8 = 1;        // CSS_KNN_LOOP=old: the round-1 main loop (k_scan_coarse) instead of k_scan_coarse8 (A/B runs)
 };
 const KnnEnv& knn_env() {
     static const KnnEnv env = [] {
@@ -1232,6 +1234,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
+        if (const char* m = getenv("CSS_KNN_LOOP")) e.loop8 = std::string(m) == "old" ? 0 : 1;
         return e;
     }();
     return env;
@@ -1565,11 +1568,16 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // v_mfma_f32_16x16x32_bf16 by default: same cycles per flop and LDS traffic as 32x32x16, but the chip holds a
     // higher clock under it (measured in one session: main stage 11.1 ms vs 12.1 ms); CSS_KNN_MFMA=32 for A/B runs
     const bool m16 = env.mfma_shape == 16;
-    const scan_fn f_stage0 = m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>;
-    const scan_fn f_mid = env.dbg ? k_scan_coarse<false, false, true>
-                                  : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>);
-    const scan_fn f_main = env.dbg ? k_scan_coarse<false, true, true>
-                                   : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>);
+    // the 8-phase ping-pong loop (k_scan_coarse8) wherever its shape constraints hold; CSS_KNN_LOOP=old for A/B runs
+    const bool loop8 = env.loop8 && m16 && ix->dpad % 128 == 0;
+    const scan_fn f_stage0 = loop8 ? k_scan_coarse8<true, false>
+                                   : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>);
+    const scan_fn f_mid = loop8 ? (env.dbg ? k_scan_coarse8<false, false, true> : k_scan_coarse8<false, false>)
+                                : (env.dbg ? k_scan_coarse<false, false, true>
+                                           : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>));
+    const scan_fn f_main = loop8 ? (env.dbg ? k_scan_coarse8<false, true, true> : k_scan_coarse8<false, true>)
+                                 : (env.dbg ? k_scan_coarse<false, true, true>
+                                            : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>));
     if (!sweep)
         for (scan_fn f : {f_stage0, f_mid, f_main})
             if ((rc = css::ensure_dynamic_lds((const void*)f, lds, ix->device)) != CSS_OK) return rc;

@@ -100,26 +100,25 @@ _Pragma("unroll")                                                               
                         }                                                                                              \
                 }                                                                                                      \
             } else {                                                                                                   \
-                float thr_m[TM];                                                                                       \
+                /* per 16-query tile m: one wave-wide vote over its TN * NR scores; only tiles with a hit walk their     \
+                   scores lane by lane (a vote over all 128 scores made ~90 % of the block tiles at 10 M rows pay a       \
+                   128-branch walk in some wave: 2.5 us per tile once the main loop no longer hid it) */                  \
 _Pragma("unroll")                                                                                                      \
-                for (int m = 0; m < TM; ++m) thr_m[m] = sthr[wr * 128 + CZ_QOFF(m)];                                   \
-                bool any = false;                                                                                      \
-_Pragma("unroll")                                                                                                      \
-                for (int m = 0; m < TM; ++m)                                                                           \
+                for (int m = 0; m < TM; ++m) {                                                                         \
+                    const float thr_q = sthr[wr * 128 + CZ_QOFF(m)];                                                   \
+                    bool any = false;                                                                                  \
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
-                        for (int r = 0; r < NR; ++r) any |= acc[m][n][r] >= thr_m[m];                                  \
-                if (__ballot(any) != 0ull) {                                                                           \
-_Pragma("unroll")                                                                                                      \
-                    for (int m = 0; m < TM; ++m) {                                                                     \
+                        for (int r = 0; r < NR; ++r) any |= acc[m][n][r] >= thr_q;                                     \
+                    if (__ballot(any) != 0ull) {                                                                       \
                         const int q = qtile * CZ_T + wr * 128 + CZ_QOFF(m);                                            \
 _Pragma("unroll")                                                                                                      \
                         for (int n = 0; n < TN; ++n)                                                                   \
 _Pragma("unroll")                                                                                                      \
                             for (int r = 0; r < NR; ++r) {                                                             \
                                 const float v = acc[m][n][r];                                                          \
-                                if (v >= thr_m[m]) {                                                                   \
+                                if (v >= thr_q) {                                                                      \
                                     const int64_t row = row0 + CZ_ROFF(n, r);                                          \
                                     if (row < ntotal && CZ_ALLOWED(mask, row)) {                                       \
                                         const int slot = atomicAdd(&cand_n[q], 1);                                     \
@@ -382,6 +381,261 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     }
 #undef CZ_ISSUE
 #undef CZ_SET_SRC
+#undef CZ_TILE_OF
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_scan_coarse8: the same stage with the 8-phase ping-pong main loop of the encoder's k_gemm8p (css_encoder_kernels.h
+// has the full description): a 64-deep K step is four phases of 16 MFMAs, each [fragment reads + 2 LDS-DMA
+// instructions] s_barrier [MFMAs] s_barrier; wave row 1 runs one barrier behind wave row 0, so one wave of every SIMD
+// issues MFMAs while its partner reads and issues DMA; half-tile slots (A = queries, B = index rows) are refilled
+// three ahead behind a counted vmcnt(6).  Accumulator geometry, thresholds, candidate appends and sibling pacing
+// are those of k_scan_coarse<.., 16> (the epilogue macro is shared).  Needs K % 128 == 0 and 256 slack rows behind
+// the shadow rows (the last tile reads them; their scores are masked by row < ntotal).
+// Measured (10 M x 768, 1000 queries, main stage): see DESIGN.md section 3.
+constexpr int C8_HT = 16384;
+constexpr int C8_A0 = 0, C8_B0 = 1, C8_B1 = 2, C8_A1 = 3;
+
+template <bool STAGE0, bool MAIN, bool DBG = false>
+__global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __restrict__ xh,
+                                                      const unsigned short* __restrict__ qh,
+                                                      const float* __restrict__ thr, float* __restrict__ cand_s,
+                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
+                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
+                                                      int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
+                                                      const float* __restrict__ xn2, int dbg_arg) {
+    constexpr int MS = 16, TM = 8, TN = 4, NR = 4;
+    const int dbg = DBG ? dbg_arg : 0;   // CSS_KNN_DBG (timing experiments): bit0 skips the epilogue
+    (void)MAIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][C8_HT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lq = lane & 15, lg = lane >> 4;
+
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int slots = per_x / nqt;
+    if (jx >= slots * nqt) return;
+    const int qtile = jx % nqt;
+    const int64_t u0 = xcd + 8 * (jx / nqt), ustep = 8 * slots;
+    const int my_ntiles = u0 < count ? (int)((count - u0 + ustep - 1) / ustep) : 0;
+    const int KT = K / 64;                 // even (host check)
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+
+    __shared__ float sthr[CZ_T];
+    __shared__ int space[4];   // landing word of the sibling-pacing counter read
+    if (tid < CZ_T) sthr[tid] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
+    __syncthreads();
+
+    int* my_cnt = pace_cnt ? pace_cnt + xcd * slots + jx / nqt : nullptr;
+    bool pace = my_cnt != nullptr && nqt > 1 && KT >= 4 && wave == 0;
+    int seen = 0;
+
+    // tile of ordinal u: STAGE0: u * stride; else (u + u / gm1 + 1) * stride (multiples of the growth factor belong to
+    // earlier stages).  u advances by ustep per tile; quotient and remainder by gm1 are carried along, so the loop
+    // holds no division.  cur_tile: the tile being computed (what the shared epilogue macro asks for).
+    const int64_t tile0 = (STAGE0 ? u0 : u0 + u0 / gm1 + 1) * stride;
+    int64_t cur_tile = tile0;
+    int ucmp = (int)u0, uqc = (int)(u0 / gm1), urc = (int)(u0 % gm1);
+#define CZ_TILE_OF(TI_) (cur_tile)
+    // ---- DMA bookkeeping.  Queries (A kinds): fixed per-lane 32-bit offsets, only the K step advances.  Index rows
+    // (B kinds): fixed per-lane offset inside a tile + a 64-bit uniform tile base that advances with the tile.
+    const int prow = lane >> 3, pchunk = lane & 7;
+    unsigned lofs[4];       // per-lane byte offset of the first piece
+    size_t tbase[4];        // uniform byte offset of the kind's current row tile (B kinds)
+    const int sq = (int)(ustep / gm1), sr = (int)(ustep % gm1);
+    int ucur[4], uq[4], ur[4];
+    int it_tile[4], it_kt[4];
+    int dsto[4];
+    dsto[C8_A0] = dsto[C8_A1] = (wr * 64 + wc * 16) * 128;
+    dsto[C8_B0] = dsto[C8_B1] = (16 * wave) * 128;
+    const unsigned row8 = 8u * (unsigned)K * 2u;
+    {
+        const int rrA = wc * 16 + prow, srowA = wr * 64 + rrA;
+        const unsigned swA = (unsigned)((pchunk ^ ((srowA >> 1) & 7)) << 4);
+        lofs[C8_A0] = (unsigned)(qtile * CZ_T + wr * 128 + rrA) * (unsigned)K * 2u + swA;
+        lofs[C8_A1] = (unsigned)(qtile * CZ_T + wr * 128 + 64 + rrA) * (unsigned)K * 2u + swA;
+        const int srowB = 16 * wave + prow;
+        const unsigned swB = (unsigned)((pchunk ^ ((srowB >> 1) & 7)) << 4);
+        lofs[C8_B0] = (unsigned)((srowB >> 5) * 64 + (srowB & 31)) * (unsigned)K * 2u + swB;
+        lofs[C8_B1] = (unsigned)((srowB >> 5) * 64 + 32 + (srowB & 31)) * (unsigned)K * 2u + swB;
+    }
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+        it_tile[kd] = 0;
+        it_kt[kd] = 0;
+        ucur[kd] = (int)u0;
+        uq[kd] = (int)(u0 / gm1);
+        ur[kd] = (int)(u0 % gm1);
+        tbase[kd] = (size_t)tile0 * CZ_T * (size_t)K * 2u;
+    }
+#define C8_ISSUE(KIND_, DB_)                                                                                  \
+    {                                                                                                         \
+        const bool isA_ = (KIND_) == C8_A0 || (KIND_) == C8_A1;                                               \
+        const char* base_ = isA_ ? reinterpret_cast<const char*>(qh) : reinterpret_cast<const char*>(xh) + tbase[KIND_]; \
+        const unsigned o0_ = lofs[KIND_] + (unsigned)it_kt[KIND_] * 128u;                                     \
+        const unsigned o1_ = (o0_ + row8) ^ 64u;                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o0_),        \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o1_),        \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_] + 1024), 16, 0, 0); \
+        if (++it_kt[KIND_] == KT) {                                                                           \
+            it_kt[KIND_] = 0;                                                                                 \
+            if (!isA_ && it_tile[KIND_] + 1 < my_ntiles) {                                                    \
+                ++it_tile[KIND_];                                                                             \
+                ucur[KIND_] += (int)ustep;                                                                    \
+                uq[KIND_] += sq;                                                                              \
+                ur[KIND_] += sr;                                                                              \
+                if (ur[KIND_] >= gm1) {                                                                       \
+                    ur[KIND_] -= gm1;                                                                         \
+                    ++uq[KIND_];                                                                              \
+                }                                                                                             \
+                const int64_t t_ = (STAGE0 ? (int64_t)ucur[KIND_] : (int64_t)ucur[KIND_] + uq[KIND_] + 1) * stride; \
+                tbase[KIND_] = (size_t)t_ * CZ_T * (size_t)K * 2u;                                            \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    typedef v4f acc_t;
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    C8_ISSUE(C8_A0, 0)
+    C8_ISSUE(C8_B0, 0)
+    C8_ISSUE(C8_B1, 0)
+    C8_ISSUE(C8_A1, 0)
+    C8_ISSUE(C8_A0, 1)
+    C8_ISSUE(C8_B0, 1)
+    C8_ISSUE(C8_B1, 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+
+    const int a_o0 = cz_swz(wr * 64 + lq, lg), a_o1 = a_o0 ^ 64;
+    const int b_o0 = cz_swz(wc * 32 + lq, lg), b_o1 = b_o0 ^ 64;
+    v4f a[4][2], b0[2][2], b1[2][2];
+#define C8_READ_A(S_, D_)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+        a[j][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? C8_A1 : C8_A0)) * C8_HT + j * 2048 + a_o0); \
+        a[j][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? C8_A1 : C8_A0)) * C8_HT + j * 2048 + a_o1); \
+    }
+#define C8_READ_B(S_, D_, B_)                                                                                 \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                           \
+        B_[n][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? C8_B1 : C8_B0)) * C8_HT + n * 2048 + b_o0); \
+        B_[n][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? C8_B1 : C8_B0)) * C8_HT + n * 2048 + b_o1); \
+    }
+// MFMA rows <- index rows, MFMA columns <- queries: lane (lq, lg) holds query 16 m + lq and rows 16 n + 4 lg + r
+#define C8_MFMA(MH_, NH_, B_)                                                                                 \
+    {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                 \
+                    acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+                        __builtin_bit_cast(v8bf, B_[n][c]), __builtin_bit_cast(v8bf, a[j][c]),                \
+                        acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                          \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
+#define C8_SYNC_A()                                   \
+    __builtin_amdgcn_sched_barrier(0);                \
+    __builtin_amdgcn_s_barrier();                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+#define C8_SYNC_B()                    \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier();      \
+    __builtin_amdgcn_sched_barrier(0);
+    int ct_tile = 0, kt = 0;
+// sibling pacing (k_scan_coarse has the rationale): announce three K steps before the tile ends, read the counter
+// one step later, wait (bounded) for the siblings before the tile's last K step
+#define C8_PACE()                                                                                             \
+    if (pace && ct_tile + 1 < my_ntiles) {                                                                    \
+        if (kt == KT - 3) {                                                                                   \
+            if (lane == 0) __hip_atomic_fetch_add(my_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+        } else if (kt == KT - 2) {                                                                            \
+            /* the counter travels by a 4-byte LDS-DMA (sc1: served by L2) into space[]: no VGPR destination, so neither \
+               the compiler (vmcnt(0) before a visible load's use) nor a late register write can hurt; it has landed   \
+               behind the counted vmcnt(6) of this K step's P4 (eight younger DMA instructions follow it) */            \
+            if (lane == 0)                                                                                    \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)my_cnt,       \
+                                                 (__attribute__((address_space(3))) void*)&space[0], 4, 0, 16);  \
+        } else if (kt == KT - 1) {                                                                            \
+            {                                                                                                 \
+                const unsigned so_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)&space[0];    \
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(so_) : "memory");   \
+            }                                                                            \
+            const int target = nqt * (ct_tile + 1);                                                           \
+            int spins = 0;                                                                                    \
+            int v = __builtin_amdgcn_readfirstlane(seen);                                                     \
+            while (v < target && spins < 64) {                                                                \
+                __builtin_amdgcn_s_sleep(8);                                                                  \
+                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
+                ++spins;                                                                                      \
+            }                                                                                                 \
+            if (v < target) pace = false;                                                                     \
+        }                                                                                                     \
+    }
+#define C8_KSTEP(D_)                                                                                          \
+    {                                                                                                         \
+        C8_PACE()                                                                                             \
+        /* P1 */                                                                                              \
+        C8_READ_B(0, D_, b0)                                                                                  \
+        C8_READ_A(0, D_)                                                                                      \
+        C8_ISSUE(C8_A1, (D_) ^ 1)                                                                             \
+        C8_SYNC_A()                                                                                           \
+        C8_MFMA(0, 0, b0)                                                                                     \
+        C8_SYNC_B()                                                                                           \
+        /* P2 */                                                                                              \
+        C8_READ_B(1, D_, b1)                                                                                  \
+        C8_ISSUE(C8_A0, D_)                                                                                   \
+        C8_SYNC_A()                                                                                           \
+        C8_MFMA(0, 1, b1)                                                                                     \
+        C8_SYNC_B()                                                                                           \
+        /* P3 */                                                                                              \
+        C8_READ_A(1, D_)                                                                                      \
+        C8_ISSUE(C8_B0, D_)                                                                                   \
+        C8_SYNC_A()                                                                                           \
+        C8_MFMA(1, 1, b1)                                                                                     \
+        C8_SYNC_B()                                                                                           \
+        /* P4 */                                                                                              \
+        C8_ISSUE(C8_B1, D_)                                                                                   \
+        if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                   \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        C8_SYNC_A()                                                                                           \
+        C8_MFMA(1, 0, b0)                                                                                     \
+        C8_SYNC_B()                                                                                           \
+        ++g;                                                                                                  \
+        ++kt;                                                                                                 \
+    }
+    for (int g = 0; g < total;) {
+        C8_KSTEP(0)
+        C8_KSTEP(1)
+        if (kt == KT) {
+            CZ_EPILOGUE();
+            kt = 0;
+            ++ct_tile;
+            ucmp += (int)ustep;
+            uqc += sq;
+            urc += sr;
+            if (urc >= gm1) {
+                urc -= gm1;
+                ++uqc;
+            }
+            cur_tile = (STAGE0 ? (int64_t)ucmp : (int64_t)ucmp + uqc + 1) * stride;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
+#undef C8_KSTEP
+#undef C8_PACE
+#undef C8_SYNC_A
+#undef C8_SYNC_B
+#undef C8_MFMA
+#undef C8_READ_A
+#undef C8_READ_B
+#undef C8_ISSUE
 #undef CZ_TILE_OF
 }
 

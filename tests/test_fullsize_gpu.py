@@ -113,8 +113,10 @@ def test_1m_clustered_rows_every_mode_matches_the_cpu_oracle():
         for mode in ("coarse", "exact_fp32"):
             ix.set_search_mode(mode)
             Da, Ia = ix.search(q[:nq], K, normalize=True)
+            # (the fp32-input MFMA scan of the exact mode sums 768 terms in one sequential fmaf chain: ~1e-6 of
+            # rounding on unit vectors, so inside these dense clusters ranks closer than 4e-6 may swap)
             assert_topk_matches(Da, Ia, Dr[:nq, :K], Ir[:nq, :K], D64[:nq, :K], f"1M clustered [{mode}] nq={nq}",
-                                D64_next=D64[:nq, K])
+                                D64_next=D64[:nq, K], tie_eps=4e-6 if mode == "exact_fp32" and nq > 16 else 1e-6)
     ix.close()
 
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ int swz_byte(int row, int chunk) { return row * 128 +
 template <int DUMMY>
 __global__ __launch_bounds__(512) void k_gemm_v0(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                  const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
-                                                 int K) {
+                                                 int K, int dbg = 0) {
     constexpr int NW = 8, WN = 4, TM = 8, TN = 4, BM = 256, BN = 256, RB = 128;
     constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB, PPW = 8;
     constexpr int E = 2 * TM;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(512) void k_gemm_v0(const bf16_t* __restrict__ A, c
             float4 bv[TN];
 #pragma unroll
             for (int n = 0; n < TN; ++n) bv[n] = *reinterpret_cast<const float4*>(&sbias[wc * 64 + 16 * n + 4 * lg]);
+            if (!(dbg & 1))
 #pragma unroll
             for (int m = 0; m < TM; ++m) {
                 char* mine = sepi[wave];
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
         /* P1 */                                                                                              \
         V1_READ_B(0, D_, b0)                                                                                  \
         V1_READ_A(0, D_)                                                                                      \
-        if constexpr (SCHED == 0) V1_ISSUE(SLOT_A1, (D_) ^ 1)                                                 \
+        if constexpr (SCHED != 1) V1_ISSUE(SLOT_A1, (D_) ^ 1)                                                 \
+        if constexpr (SCHED == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                           \
         V1_SYNC_A()                                                                                           \
         V1_MFMA(0, 0, b0)                                                                                     \
         V1_SYNC_B()                                                                                           \
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
         V1_READ_B(1, D_, b1)                                                                                  \
         V1_ISSUE(SLOT_A0, D_)                                                                                 \
         if (kt == 0 && ct_tile + 1 < my_ntiles) V1_BIAS(ct_tile + 1)                                          \
+        if constexpr (SCHED == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                           \
         V1_SYNC_A()                                                                                           \
         V1_MFMA(0, 1, b1)                                                                                     \
         V1_SYNC_B()                                                                                           \
@@ -398,6 +401,8 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
             V1_ISSUE(SLOT_A1, D_)                                                                             \
             if (g + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        } else if constexpr (SCHED == 2) {                                                                    \
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                 \
         } else {                                                                                              \
             if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                               \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
@@ -495,6 +500,7 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
             ++ct_tile;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may still be landing in LDS when the block ends
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
 }
 
@@ -550,11 +556,11 @@ int main(int argc, char** argv) {
     grid = std::max(8, grid / 8 * 8);
     const size_t lds = 131072;
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v0<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&](int v) {
-        if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K);
-        else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 1>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 2>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else hipLaunchKernelGGL((k_gemm_v1<0, false, 0>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
     };
     // ---- correctness: sampled elements against an fp64 host reference

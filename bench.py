@@ -444,7 +444,7 @@ def main():
             main_rows = min(main_tiles * 256, shard)
             flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
             sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
-            roofline = {"bound": "mfma", "kernel": "k_scan_coarse<false,true,false,16> (main stage of the cascade)",
+            roofline = {"bound": "mfma", "kernel": "k_scan_coarse8<false,true> (main stage of the cascade)",
                         "achieved": flops / avg_s / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None,
                         "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows,
@@ -461,7 +461,9 @@ def main():
                         "unit": "GB/s", "frac": sweep_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "launches": n, "avg_ms": ms / n}
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
-        tr = pmc_traffic({"knn_scan_coarse_main": "k_scan_coarse<false, true"}.get(dom, "k_scan_small"), wl)
+        tr = None
+        for pref in ({"knn_scan_coarse_main": ("k_scan_coarse8<false, true", "k_scan_coarse<false, true")}.get(dom, ("k_scan_small",))):
+            tr = tr or pmc_traffic(pref, wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]

@@ -21,6 +21,7 @@ _LAZY = {
     "EmbeddingConfig": ".embeddings",
     "EmbeddingStats": ".embeddings",
     "EmbeddingGenerator": ".embeddings",
+    "EmbeddingBatcher": ".embeddings",
     "IndexFlat": ".flat_index",
     "IndexFlatIP": ".flat_index",
     "IndexFlatL2": ".flat_index",

@@ -386,8 +386,9 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
             ProfScope ps("enc_attention", st);
             if constexpr (BF) {
                 const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1) * 4;
-                hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B, (max_len + 127) / 128, c.heads), dim3(256), lds, st,
-                                   (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx);
+                const int nqb = (max_len + 127) / 128;
+                hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st,
+                                   (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);
             } else {
                 hipLaunchKernelGGL(k_attention_f32, dim3(B, max_len, c.heads), dim3(64), 0, st, (const float*)e->qkv, cu,
                                    e->bias_tab, maxL, H, (float*)e->ctx);

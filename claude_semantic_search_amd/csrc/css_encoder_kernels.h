@@ -1046,14 +1046,21 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const TIn* __restrict__ A, 
 template <int HD>
 __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,
-                                                        bf16_t* __restrict__ ctx) {
+                                                        bf16_t* __restrict__ ctx, int nqb, int heads) {
     static_assert(HD == 64, "head_dim 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                 // [2][64 keys][128 B]  (swizzled)
     char* Vs = smem + 2 * 8192;      // [2][64 keys][128 B]  (row-major, d contiguous)
     float* bt = reinterpret_cast<float*>(smem + 4 * 8192);  // [2*maxL-1]
 
-    const int b = blockIdx.x, qb = blockIdx.y, head = blockIdx.z;
+    // 1-D grid of B * nqb * heads blocks.  The nqb query blocks of one (sequence, head) read the same K / V rows:
+    // they get consecutive slots of ONE XCD (blocks l, l + 8, l + 16, ... share an XCD under round-robin dispatch;
+    // speed only), so K / V come from HBM once and from that XCD's L2 afterwards.
+    const int nwork = gridDim.x;
+    const int xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
+    const int qx = nwork / 8, rx = nwork % 8;
+    const int work = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + ix;   // bijective (T1)
+    const int qb = work % nqb, head = (work / nqb) % heads, b = work / (nqb * heads);
     const int tok0 = cu[b];
     const int L = cu[b + 1] - tok0;
     const int q0 = qb * 128;

@@ -25,7 +25,7 @@ import logging
 import os
 import time
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional
+from typing import Any, Callable, Dict, Hashable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -62,6 +62,74 @@ class EmbeddingStats:
     average_chunk_length: float = 0.0
     throughput_chunks_per_second: float = 0.0
     model_info: Dict[str, Any] = field(default_factory=dict)
+
+
+class EmbeddingBatcher:
+    """Cross-file batching of the index pipeline.
+
+    The reference encodes one conversation file at a time (``src/cli.py:120-169``: ``generate_embeddings(chunks)``
+    per file), so on a GPU whose batch is 256 almost every device batch is ragged and small.  This accumulator takes
+    the chunk lists of many files, encodes them in FULL batches (``flush_at`` texts per ``model.encode`` call, a
+    multiple of the device batch; the encoder length-sorts inside a call) and hands every file back -- through
+    ``on_file_done(key, chunks, rows)`` -- as soon as all of its chunks are embedded, in submission order, so that
+    the caller can run ``storage.add_chunks(chunks)`` / ``update_file_info`` exactly as the reference does per file.
+
+    ``chunk.embedding`` is written as ``generate_embeddings`` writes it (a list, or an ndarray row with
+    ``EmbeddingConfig.embeddings_as_arrays``).  A file may be larger than ``flush_at``; empty files complete at once.
+    """
+
+    def __init__(self, generator: "EmbeddingGenerator", on_file_done: Optional[Callable] = None,
+                 flush_at: Optional[int] = None):
+        self.gen = generator
+        self.on_file_done = on_file_done
+        self._flush_at = flush_at
+        self._pending: List[Tuple[Hashable, List[Chunk], List[Optional[np.ndarray]], int]] = []  # key, chunks, rows, done
+        self._queue: List[Tuple[int, int]] = []     # (index into _pending, chunk index) awaiting an encode
+        self._base = 0                               # files completed and dropped from the front of _pending
+        self.batches: List[int] = []                 # sizes of the encode calls made (diagnostics / tests)
+
+    @property
+    def flush_at(self) -> int:
+        if self._flush_at:
+            return int(self._flush_at)
+        return 16 * max(1, int(self.gen.config.batch_size))
+
+    def add(self, key: Hashable, chunks: List[Chunk]) -> None:
+        """Queue one file's chunks; encodes whenever a full ``flush_at`` texts are waiting."""
+        slot = self._base + len(self._pending)
+        self._pending.append((key, chunks, [None] * len(chunks), 0))
+        self._queue.extend((slot, i) for i in range(len(chunks)))
+        if not chunks:
+            self._complete_ready()
+        while len(self._queue) >= self.flush_at:
+            self._encode(self.flush_at)
+
+    def flush(self) -> None:
+        """Encode whatever is still waiting (the last, possibly ragged batch) and complete every file."""
+        while self._queue:
+            self._encode(min(len(self._queue), self.flush_at))
+        self._complete_ready()
+
+    def _encode(self, n: int) -> None:
+        take, self._queue = self._queue[:n], self._queue[n:]
+        texts = [self._pending[s - self._base][1][i].text for s, i in take]
+        rows = self.gen._generate_embeddings_batch(texts)
+        self.batches.append(len(texts))
+        for (s, i), row in zip(take, rows):
+            key, chunks, out, done = self._pending[s - self._base]
+            out[i] = row
+            chunks[i].embedding = row if self.gen.config.embeddings_as_arrays else row.tolist()
+            self._pending[s - self._base] = (key, chunks, out, done + 1)
+        self._complete_ready()
+
+    def _complete_ready(self) -> None:
+        # files complete strictly in submission order (the queue is FIFO), so only the front can be ready
+        while self._pending and self._pending[0][3] == len(self._pending[0][1]):
+            key, chunks, out, _ = self._pending.pop(0)
+            self._base += 1
+            if self.on_file_done is not None:
+                rows = np.stack(out) if out else np.zeros((0, self.gen._embedding_dim or 768), dtype=np.float32)
+                self.on_file_done(key, chunks, rows)
 
 
 def SentenceTransformer(model_name_or_path: str, cache_folder: Optional[str] = None, **kwargs):
@@ -133,6 +201,23 @@ class EmbeddingGenerator:
             for chunk, row in zip(chunks, embeddings):
                 chunk.embedding = row.tolist()
         return embeddings
+
+    def generate_embeddings_many(self, chunk_lists: Sequence[List[Chunk]], flush_at: Optional[int] = None) -> List[np.ndarray]:
+        """The chunks of MANY files through full device batches (``EmbeddingBatcher``): per file the same result as
+        ``generate_embeddings(chunks)`` -- ``chunk.embedding`` set, an ``[n_i, 768]`` array returned -- without the
+        ragged per-file batches of the reference's loop (``src/cli.py:120-169``)."""
+        if not self.model:
+            self.load_model()
+        out: List[Optional[np.ndarray]] = [None] * len(chunk_lists)
+
+        def done(key, _chunks, rows):
+            out[key] = rows
+
+        b = EmbeddingBatcher(self, on_file_done=done, flush_at=flush_at)
+        for i, chunks in enumerate(chunk_lists):
+            b.add(i, chunks)
+        b.flush()
+        return out  # type: ignore[return-value]
 
     def generate_single_embedding(self, text: str) -> np.ndarray:
         if not self.model:

@@ -42,6 +42,9 @@ from . import flat_index as fi
 from .chunk import Chunk
 from .gpu_utils import GPUCapability, assess_gpu_capability, log_gpu_status
 
+# bytes in front of the row data of faiss' IndexFlat file: fourcc, d, ntotal, 2 dummies, is_trained, metric, n_floats
+_INDEX_HEADER_BYTES = 4 + 4 + 8 + 16 + 1 + 4 + 8
+
 
 @dataclass
 class StorageConfig:
@@ -129,7 +132,8 @@ class HybridStorage:
         self._is_gpu_index: bool = False
         self._lock = threading.RLock()
         self._saved_rows = -1  # rows known to be in index_path (-1: unknown)
-        self._allow_cache: Dict[str, Any] = {}  # filter key -> (id-map size, ntotal, allow mask); push-down only
+        self._allow_cache: Dict[str, Any] = {}  # filter key -> (stamp, allow mask); push-down only
+        self._mutations = 0  # bumped by every change of the chunk set (part of the allow-cache stamp)
 
         self.total_chunks: int = 0
         self.embedding_dim: int = self.config.embedding_dim
@@ -203,6 +207,7 @@ class HybridStorage:
             self._init_faiss()
 
     def _rebuild_id_mappings(self) -> None:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         cur = self.db.cursor()
         cur.execute("SELECT id, faiss_id FROM chunks WHERE faiss_id IS NOT NULL")
         fwd: Dict[str, int] = {}
@@ -217,6 +222,7 @@ class HybridStorage:
 
     # ------------------------------------------------------------------ add
     def add_chunks(self, chunks: List[Chunk]) -> None:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         if not chunks:
             return
         with_emb = [c for c in chunks if c.embedding is not None]
@@ -312,7 +318,7 @@ class HybridStorage:
         semantics of ``_matches_filters``.  One pass over the chunks table, cached until the id maps change."""
         key = json.dumps(filters, sort_keys=True, default=str)
         hit = self._allow_cache.get(key)
-        stamp = (len(self.faiss_id_to_chunk_id), ntotal, self.total_chunks)
+        stamp = (self._mutations, len(self.faiss_id_to_chunk_id), ntotal, self.total_chunks)
         if hit is not None and hit[0] == stamp:
             return hit[1]
         allow = np.zeros(ntotal, dtype=bool)
@@ -389,6 +395,7 @@ class HybridStorage:
         return self._chunks_where("project_name", project_name)
 
     def delete_chunk(self, chunk_id: str) -> bool:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         with self._lock:
             fid = self.chunk_id_to_faiss_id.get(chunk_id)
             if fid is None:
@@ -405,6 +412,7 @@ class HybridStorage:
             return True
 
     def delete_chunks_by_session(self, session_id: str) -> int:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         if not self.db:
             raise RuntimeError("Database not initialized")
         cur = self.db.cursor()
@@ -493,6 +501,7 @@ class HybridStorage:
         return current > datetime.fromisoformat(row["last_modified"])
 
     def remove_chunks_for_file(self, file_path: str) -> int:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         with self._lock:
             cur = self.db.cursor()
             doomed = cur.execute("SELECT id, faiss_id FROM chunks WHERE file_path = ?", (file_path,)).fetchall()
@@ -507,6 +516,7 @@ class HybridStorage:
             return len(doomed)
 
     def clear_all_data(self) -> None:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         with self._lock:
             self.faiss_index = self._create_cpu_index()
             self._saved_rows = -1
@@ -537,16 +547,34 @@ class HybridStorage:
                 if n > self._saved_rows:
                     new_rows = ix.reconstruct_n(self._saved_rows, n - self._saved_rows)
                     with open(path, "r+b") as f:
+                        # rows first, made durable, THEN the two header counters: a crash in between leaves a
+                        # file whose header still describes the old, complete prefix (trailing bytes are ignored
+                        # by read_index), never a header that promises rows the file does not hold
+                        f.seek(_INDEX_HEADER_BYTES + self._saved_rows * ix.d * 4)
+                        f.write(new_rows.tobytes())
+                        f.truncate()
+                        f.flush()
+                        os.fsync(f.fileno())
                         f.seek(8)
                         f.write(struct.pack("<q", n))
                         f.seek(8 + 8 + 16 + 1 + 4)
                         f.write(struct.pack("<Q", n * ix.d))
-                        f.seek(0, os.SEEK_END)
-                        f.write(new_rows.tobytes())
+                        f.flush()
+                        os.fsync(f.fileno())
             else:
-                fi.write_index(ix, path)
+                self._write_index_atomically(ix, path)
             self._saved_rows = n
         self.logger.info(f"Saved flat index ({n} vectors) to {self.index_path}")
+
+    @staticmethod
+    def _write_index_atomically(ix, path: str) -> None:
+        """Whole-file write through a temporary sibling + ``os.replace``: readers (and a crash) see the old file or
+        the new one, never a torn one."""
+        tmp = path + ".tmp"
+        fi.write_index(ix, tmp)
+        with open(tmp, "rb") as f:
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
 
     def backup(self, backup_dir: str) -> None:
         dest = Path(backup_dir)
@@ -560,6 +588,7 @@ class HybridStorage:
         self.logger.info(f"Backup created in {dest}")
 
     def restore(self, backup_dir: str) -> None:
+        self._mutations += 1  # invalidates cached allow masks (filter push-down)
         src = Path(backup_dir)
         with self._lock:
             ipath = src / self.config.index_name
@@ -614,11 +643,18 @@ class HybridStorage:
                 self.chunk_id_to_faiss_id[row["id"]] = new_id
                 self.faiss_id_to_chunk_id[new_id] = row["id"]
                 updates.append((new_id, row["id"]))
+            # the renumbered ids only make sense with the compacted rows: put the new index file in place (atomically)
+            # before the SQLite commit, whatever auto_save says -- otherwise a crash, or auto_save=False, would pair
+            # the new ids with the old tombstoned file at the next start and searches would return the wrong chunks.
+            # (A crash between the two steps leaves new file + old ids: detected at load by ntotal != max id + 1 for a
+            # compaction that removed rows, and repaired by re-running optimize().)
             cur.executemany("UPDATE chunks SET faiss_id = ? WHERE id = ?", updates)
+            self._write_index_atomically(fresh, str(self.index_path))
             self.db.commit()
             self.faiss_index = fresh
-            self._saved_rows = -1
+            self._saved_rows = fresh.ntotal
             self.total_chunks = len(live)
+            self._mutations += 1
             old.close()
         self.logger.info("Flat index rebuilt")
 

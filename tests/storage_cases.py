@@ -304,6 +304,65 @@ class StorageCases:
         assert results[False] == []                                # starved inside the first 100 unfiltered hits
         assert len(results[True]) == 5 and all(int(c[1:]) % 50 == 7 for c in results[True])
 
+    def test_compaction_is_on_disk_before_the_new_ids_are_committed(self):
+        """optimize() renumbers faiss ids in SQLite; the compacted rows must already be in the index file then, also
+        with auto_save=False and without close(): a process that dies right after must find ids and rows that match."""
+        self.storage.initialize()
+        self.storage.add_chunks(self.chunks)
+        self.storage.save_index()
+        assert self.storage.delete_chunk("chunk_001")
+        self.storage.optimize()                                # no save_index(), no close() afterwards: "crash"
+        other = HybridStorage(self.config)                     # a second process opening the same data_dir
+        other.initialize()
+        assert other.faiss_index.ntotal == 2 and other.total_chunks == 2
+        res = other.search(np.array([0.9, 0.1, 0.2, 0.3]))
+        assert res[0].chunk_id == "chunk_003" and abs(res[0].similarity - 1.0) < 1e-5
+        assert [r.chunk_id for r in other.search(np.array([0.5, 0.6, 0.7, 0.8]))][0] == "chunk_002"
+        assert not (self.storage.index_path.parent / (self.storage.index_path.name + ".tmp")).exists()
+        other.close()
+
+    def test_appended_rows_are_durable_before_the_header_counts_them(self):
+        """save_index() appends new rows first and patches the header afterwards: a file cut off right behind the old
+        rows + a stale header still loads as the old, complete index (trailing bytes are ignored)."""
+        import struct
+
+        self.storage.initialize()
+        self.storage.add_chunks(self.chunks[:2])
+        self.storage.save_index()
+        before = self.storage.index_path.read_bytes()
+        self.storage.add_chunks(self.chunks[2:])
+        self.storage.save_index()                              # append path
+        after = self.storage.index_path.read_bytes()
+        assert len(after) == len(before) + 4 * 4 and after[45:len(before)] == before[45:]
+        assert struct.unpack("<q", after[8:16])[0] == 3 and struct.unpack("<Q", after[37:45])[0] == 12
+        # what a crash between "rows durable" and "header patched" leaves behind: old header + appended rows
+        torn = before[:45] + after[45:]
+        self.storage.index_path.write_bytes(torn)
+        s2 = HybridStorage(self.config)
+        s2.initialize()
+        assert s2.faiss_index.ntotal == 2
+        s2.close()
+
+    def test_allow_mask_cache_is_dropped_when_the_chunk_set_changes(self):
+        """Filter push-down caches one allow mask per filter; clearing and re-adding the SAME NUMBER of chunks with other
+        metadata must not reuse the old mask."""
+        cfg = StorageConfig(data_dir=self.tmp, embedding_dim=4, auto_save=False, db_name="ac.db", index_name="ac.faiss",
+                            filter_pushdown=True)
+        s = HybridStorage(cfg)
+        s.initialize()
+        s.add_chunks(self.chunks)
+        sc = SearchConfig(top_k=3, similarity_threshold=-1.0)
+        q = np.array([0.1, 0.2, 0.3, 0.4])
+        assert [r.chunk_id for r in s.search(q, sc, {"project_name": "other_project"})] == ["chunk_003"]
+        s.clear_all_data()
+        swapped = _chunks()
+        swapped[0].metadata["project_name"], swapped[2].metadata["project_name"] = "other_project", "test_project"
+        s.add_chunks(swapped)                                  # same ids, same count, other projects
+        assert [r.chunk_id for r in s.search(q, sc, {"project_name": "other_project"})] == ["chunk_001"]
+        assert s.delete_chunk("chunk_001")
+        assert s.search(q, sc, {"project_name": "other_project"}) == []
+        s.close()
+
     def test_context_manager(self):
         with HybridStorage(self.config) as s:
             s.add_chunks(self.chunks)

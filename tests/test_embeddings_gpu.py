@@ -133,3 +133,36 @@ def test_config1_shape_encode_index_search_vs_the_reference_path():
     assert (np.take_along_axis(full, I, axis=1) >= Dr[:, -1:] - 2e-3).all()
     enc.close()
     ix.close()
+
+
+def test_cross_file_batching_gives_the_per_file_embeddings():
+    """generate_embeddings_many / EmbeddingBatcher: 40 'files' of 1..60 chunks through full device batches must give,
+    chunk for chunk, what the reference's per-file loop gives (bf16 mode: another batch shape means another GEMM tile
+    walk, so equality is to rounding noise, cos >= 1 - 1e-5), and index + search on both must agree."""
+    import random
+
+    from claude_semantic_search_amd.chunk import Chunk
+    from claude_semantic_search_amd.embeddings import EmbeddingBatcher, EmbeddingConfig, EmbeddingGenerator
+
+    rng = random.Random(3)
+    words = ["error", "python", "index", "search", "vector", "claude", "session", "tool", "test", "kernel", "query", "fix"]
+    files = [[Chunk(f"f{f}_{i}", " ".join(rng.choice(words) for _ in range(rng.randint(3, 120))), {"file": f})
+              for i in range(rng.randint(1, 60))] for f in range(40)]
+    cfg = EmbeddingConfig(synthetic_weights_seed=5, batch_size=256, show_progress=False, embeddings_as_arrays=True,
+                          use_gpu=True, auto_batch_size=False)
+    g = EmbeddingGenerator(cfg)
+    g.load_model()
+    per_file = [g.generate_embeddings([Chunk(c.id, c.text, {}) for c in chunks]) for chunks in files]
+    order = []
+    b = EmbeddingBatcher(g, on_file_done=lambda key, chunks, rows: order.append(key))
+    many = g.generate_embeddings_many(files)
+    total = sum(len(f) for f in files)
+    for a, m in zip(per_file, many):
+        assert a.shape == m.shape
+        assert ((a * m).sum(1)).min() > 1 - 1e-5 and np.abs(a - m).max() < 5e-3
+    assert all(isinstance(c.embedding, np.ndarray) and c.embedding.shape == (768,) for f in files for c in f)
+    # the batcher made ceil(total / 4096) encode calls instead of 40
+    for f, chunks in enumerate(files):
+        b.add(f, chunks)
+    b.flush()
+    assert order == list(range(40)) and len(b.batches) == -(-total // b.flush_at) and sum(b.batches) == total

@@ -134,3 +134,59 @@ def test_benchmark_and_info_keys(st):  # :353-419
     for key in ("model_name", "embedding_dimension", "max_seq_length", "device", "batch_size", "use_gpu", "gpu_available"):
         assert key in info
     assert g.is_using_gpu  # device string contains "cuda" (what PyTorch-ROCm calls a HIP device)
+
+
+# ---- cross-file batching (the reference encodes file by file, src/cli.py:120-169) ----
+def _hash_model(dim=5):
+    """Deterministic stand-in for the encoder: a text's embedding depends on the text alone."""
+    m = _mock_model(dim)
+
+    def encode(texts, **_kw):
+        if isinstance(texts, str):
+            texts = [texts]
+        return np.array([[float((hash(t) >> (8 * j)) % 251) for j in range(dim)] for t in texts], dtype=np.float32)
+
+    m.encode.side_effect = encode
+    return m
+
+
+@patch(SEAM)
+def test_batcher_runs_full_batches_and_completes_files_in_order(st):
+    from claude_semantic_search_amd.embeddings import EmbeddingBatcher
+
+    st.return_value = _hash_model()
+    g = EmbeddingGenerator(EmbeddingConfig(batch_size=4, show_progress=False))
+    g.load_model()
+    sizes = [3, 0, 10, 1, 7, 25, 4]                       # chunks per file; one empty, one larger than flush_at
+    files = [[Chunk(f"f{f}c{i}", f"text {f}/{i}", {}) for i in range(n)] for f, n in enumerate(sizes)]
+    done = []
+    b = EmbeddingBatcher(g, on_file_done=lambda key, chunks, rows: done.append((key, len(chunks), rows.shape)), flush_at=8)
+    for f, chunks in enumerate(files):
+        b.add(f, chunks)
+    assert all(n == 8 for n in b.batches) and len(b.batches) == sum(sizes) // 8      # only full batches so far
+    assert [d[0] for d in done] == list(range(len(done)))                            # submission order
+    b.flush()
+    assert b.batches[-1] == sum(sizes) % 8 and sum(b.batches) == sum(sizes)
+    assert [d[0] for d in done] == list(range(len(sizes))) and [d[1] for d in done] == sizes
+    assert all(d[2] == (n, 5) for d, n in zip(done, sizes))
+    # every chunk got the embedding of ITS text, as a list (reference behaviour, src/embeddings.py:175)
+    for chunks in files:
+        for c in chunks:
+            assert isinstance(c.embedding, list) and c.embedding == g.model.encode([c.text])[0].tolist()
+    # encode kwargs are those of generate_embeddings (src/embeddings.py:216-222)
+    kw = g.model.encode.call_args_list[0].kwargs
+    assert kw["batch_size"] == 4 and kw["normalize_embeddings"] is True and kw["convert_to_numpy"] is True
+
+
+@patch(SEAM)
+def test_generate_embeddings_many_equals_per_file_calls(st):
+    st.return_value = _hash_model()
+    g = EmbeddingGenerator(EmbeddingConfig(batch_size=2, show_progress=False, embeddings_as_arrays=True))
+    files = [[Chunk(f"a{i}", f"alpha {i}", {}) for i in range(5)], [], [Chunk("b0", None, {}), Chunk("b1", "   ", {})]]
+    many = g.generate_embeddings_many(files, flush_at=4)
+    assert [m.shape for m in many] == [(5, 5), (0, 5), (2, 5)]
+    for chunks, rows in zip(files, many):
+        if chunks:
+            ref = g.generate_embeddings([Chunk(c.id, c.text, {}) for c in chunks])   # same sanitising per text
+            assert np.array_equal(rows, ref)
+            assert all(isinstance(c.embedding, np.ndarray) for c in chunks)

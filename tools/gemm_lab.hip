@@ -371,8 +371,54 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
 
     int ct_tile = 0, kt = 0;
 // one K step on buffer D_ (compile-time 0 / 1)
-#define V1_KSTEP(D_)                                                                                          \
+// MFMA cluster with the phase's DMA issue inside it (SCHED 3): 8 MFMAs, the two DMA instructions, 8 MFMAs
+#define V1_MFMA_I(MH_, NH_, B_, KIND_, DB_)                                                                   \
     {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
+                acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                    __builtin_bit_cast(v8bf, B_[n][0]), __builtin_bit_cast(v8bf, a[j][0]),                    \
+                    acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        V1_ISSUE(KIND_, DB_)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
+                acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                    __builtin_bit_cast(v8bf, B_[n][1]), __builtin_bit_cast(v8bf, a[j][1]),                    \
+                    acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                              \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
+#define V1_KSTEP(D_)                                                                                          \
+    if constexpr (SCHED == 3) {                                                                               \
+        /* P1 */                                                                                              \
+        V1_READ_B(0, D_, b0)                                                                                  \
+        V1_READ_A(0, D_)                                                                                      \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* B_1 of this K step has landed (read in P2) */    \
+        V1_SYNC_A()                                                                                           \
+        V1_MFMA_I(0, 0, b0, SLOT_A1, (D_) ^ 1)                                                                \
+        V1_SYNC_B()                                                                                           \
+        /* P2 */                                                                                              \
+        V1_READ_B(1, D_, b1)                                                                                  \
+        if (kt == 0 && ct_tile + 1 < my_ntiles) V1_BIAS(ct_tile + 1)                                          \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* A_1 of this K step has landed (read in P3) */    \
+        V1_SYNC_A()                                                                                           \
+        V1_MFMA_I(0, 1, b1, SLOT_A0, D_)                                                                      \
+        V1_SYNC_B()                                                                                           \
+        /* P3 */                                                                                              \
+        V1_READ_A(1, D_)                                                                                      \
+        V1_SYNC_A()                                                                                           \
+        V1_MFMA_I(1, 1, b1, SLOT_B0, D_)                                                                      \
+        V1_SYNC_B()                                                                                           \
+        /* P4 */                                                                                              \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* A_0, B_0 of the next K step have landed */       \
+        V1_SYNC_A()                                                                                           \
+        V1_MFMA_I(1, 0, b0, SLOT_B1, D_)                                                                      \
+        V1_SYNC_B()                                                                                           \
+        ++g;                                                                                                  \
+        ++kt;                                                                                                 \
+    } else {                                                                                                  \
         /* P1 */                                                                                              \
         V1_READ_B(0, D_, b0)                                                                                  \
         V1_READ_A(0, D_)                                                                                      \
@@ -406,7 +452,7 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
         } else {                                                                                              \
             if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                               \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-        }                                                 \
+        }                                                                                                     \
         V1_SYNC_A()                                                                                           \
         V1_MFMA(1, 0, b0)                                                                                     \
         V1_SYNC_B()                                                                                           \
@@ -556,11 +602,11 @@ int main(int argc, char** argv) {
     grid = std::max(8, grid / 8 * 8);
     const size_t lds = 131072;
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v0<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&](int v) {
         if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
-        else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 2>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 3>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else hipLaunchKernelGGL((k_gemm_v1<0, false, 0>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
     };
     // ---- correctness: sampled elements against an fp64 host reference

@@ -8,7 +8,7 @@ Each DIR is the `-d` directory of one rocprofv3 counter pass over the same bench
 MI355X_MICROARCH.md's HBM section: counter unit = KiB; on gfx950 FETCH_SIZE reports half of the bytes of
 a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  Infinity-Cache hits are counted
 by FETCH_SIZE, so for kernels that re-read through L2/MALL the figure is an upper bound on HBM bytes.
-bench.py reads the resulting file for `roofline.traffic`.
+bench.py reads the resulting file for `roofline.traffic`.  Averages are over a kernel's full-size launches (see collect()).
 """
 import csv
 import glob
@@ -24,22 +24,34 @@ def short(name: str) -> str:
     return m.group(1) + (m.group(2) or "")
 
 
+ALL_LAUNCHES = False   # --all: keep every launch (a run that only holds one workload, e.g. the encoder at its fixed shape)
+
+
 def collect(d: str, counter: str):
-    acc = {}
+    """Per kernel: [sum of counter, launches, sum of ms] over its FULL-SIZE launches -- those lasting at least half as
+    long as the kernel's longest launch.  One bench run launches a kernel on several workloads (the 10 M-row index of
+    the headline, the 1 M-row indexes of the clustered extra, warm-ups of other shapes); the headline's launches are
+    the long ones, and only they are comparable with its algorithmic bytes."""
+    rows = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] != counter:
                     continue
                 k = short(row["Kernel_Name"])
-                a = acc.setdefault(k, [0.0, 0, 0.0])
-                a[0] += float(row["Counter_Value"])
-                a[1] += 1
-                a[2] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+                rows.setdefault(k, []).append((float(row["Counter_Value"]),
+                                               (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
+    acc = {}
+    for k, lst in rows.items():
+        longest = max(ms for _, ms in lst)
+        keep = [(v, ms) for v, ms in lst if ALL_LAUNCHES or ms >= 0.5 * longest]
+        acc[k] = [sum(v for v, _ in keep), len(keep), sum(ms for _, ms in keep)]
     return acc
 
 
 def main():
+    global ALL_LAUNCHES
+    ALL_LAUNCHES = "--all" in sys.argv
     fetch_dir, write_dir, out = sys.argv[1:4]
     note = ""
     if "--note" in sys.argv:

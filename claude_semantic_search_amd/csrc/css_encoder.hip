@@ -37,7 +37,35 @@ struct Param {
 struct LayerW {
     float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
     bf16_t *wqkv_h, *wo_h, *w1_h, *w2_h;
+    // LayerNorm-folded operands (k_fold_ln): the QKV weight carries gamma of the LayerNorm BEFORE this layer
+    // (embedding LN / previous layer's output LN), the FFN1 weight gamma of this layer's attention LN
+    bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
+    float *dqkv = nullptr, *d1 = nullptr;   // d rows of the two folded GEMMs
+    float *bo_f = nullptr, *b2_f = nullptr; // bias + beta of the LayerNorm whose output is the residual (EPI_RES)
 };
+
+// Process-wide switches, read from the environment ONCE (thread-safe static init); all are A/B-experiment knobs,
+// the defaults are the product configuration.
+struct EncEnv {
+    int resid = 2;        // CSS_ENC_RESID: residual stream storage in bf16 mode (see forward_typed)
+    int dbg = 0;          // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
+    bool big_tiles = true;   // CSS_GEMM_TILE=128: the 128x128 tiles everywhere
+    bool mfma16 = true;      // CSS_GEMM_MFMA=32: 32x32x16 MFMA kernel (k_gemm) instead of k_gemm16
+    bool loop8 = true;       // CSS_GEMM_LOOP=old: the round-1 main loop (k_gemm16) instead of k_gemm8p
+    bool fuse_ln = true;     // CSS_ENC_FUSE_LN=0: separate LayerNorm kernels also for large batches
+    EncEnv() {
+        if (const char* t = getenv("CSS_GEMM_TILE")) big_tiles = atoi(t) != 128;
+        if (const char* t = getenv("CSS_GEMM_DBG")) dbg = atoi(t);
+        if (const char* t = getenv("CSS_ENC_RESID")) resid = atoi(t);
+        if (const char* t = getenv("CSS_GEMM_MFMA")) mfma16 = atoi(t) != 32;
+        if (const char* t = getenv("CSS_GEMM_LOOP")) loop8 = std::string(t) != "old";
+        if (const char* t = getenv("CSS_ENC_FUSE_LN")) fuse_ln = atoi(t) != 0;
+    }
+};
+const EncEnv& enc_env() {
+    static const EncEnv env;
+    return env;
+}
 
 __global__ void k_synth_fill(float* p, size_t n, uint64_t seed, float mean, float std) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,6 +121,8 @@ struct css_encoder {
     int cap_tokens = 0, cap_seqs = 0, num_cus = 256;
     float *x32 = nullptr, *pre32 = nullptr;          // [T, H] fp32
     void *x16 = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;  // operand-typed
+    long long* stats[2] = {nullptr, nullptr};        // [T][2] fixed-point row sums of the two pre tensors (folded-LN path)
+    bool x32_valid = true;                           // false after a folded-LN forward (x32 is not materialised there)
     int32_t *ids_dev = nullptr, *cu_dev = nullptr;
     float* out_dev = nullptr;
     // hipGraph cache for the launch-bound tiny-batch path (generate_single_embedding): key =
@@ -171,6 +201,14 @@ int build_params(css_encoder* e) {
         CSS_HIP_TRY(hipMalloc((void**)&L.wo_h, (size_t)H * H * 2));
         CSS_HIP_TRY(hipMalloc((void**)&L.w1_h, (size_t)F * H * 2));
         CSS_HIP_TRY(hipMalloc((void**)&L.w2_h, (size_t)H * F * 2));
+        if (c.compute == 0) {
+            CSS_HIP_TRY(hipMalloc((void**)&L.wqkv_f, (size_t)3 * H * H * 2));
+            CSS_HIP_TRY(hipMalloc((void**)&L.w1_f, (size_t)F * H * 2));
+            CSS_HIP_TRY(hipMalloc((void**)&L.dqkv, (size_t)3 * H * 4));
+            CSS_HIP_TRY(hipMalloc((void**)&L.d1, (size_t)F * 4));
+            CSS_HIP_TRY(hipMalloc((void**)&L.bo_f, (size_t)H * 4));
+            CSS_HIP_TRY(hipMalloc((void**)&L.b2_f, (size_t)H * 4));
+        }
     }
 #undef AP
     const int maxL = c.max_seq_len;
@@ -187,6 +225,19 @@ int finalize_weights(css_encoder* e) {
     const css_encoder_cfg& c = e->cfg;
     const size_t H = c.hidden, F = c.ffn;
     hipStream_t st = e->stream;
+    for (size_t li = 0; li < e->layers.size(); ++li) {
+        LayerW& L = e->layers[li];
+        if (L.wqkv_f) {
+            const float* g_in = li == 0 ? e->embg : e->layers[li - 1].ln2g;
+            const float* b_in = li == 0 ? e->embb : e->layers[li - 1].ln2b;
+            hipLaunchKernelGGL(k_fold_ln, dim3((3 * H + 3) / 4), dim3(256), 0, st, L.wqkv, g_in, b_in, L.bqkv, (int)(3 * H),
+                               (int)H, L.wqkv_f, L.dqkv);
+            hipLaunchKernelGGL(k_fold_ln, dim3((F + 3) / 4), dim3(256), 0, st, L.w1, L.ln1g, L.ln1b, L.b1, (int)F, (int)H,
+                               L.w1_f, L.d1);
+            hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.bo, b_in, L.bo_f, (int)H);
+            hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.b2, L.ln1b, L.b2_f, (int)H);
+        }
+    }
     for (auto& L : e->layers) {
         hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.wqkv, L.wqkv_h, 3 * H * H);
         hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, st, L.wo, L.wo_h, H * H);
@@ -213,7 +264,7 @@ int ensure_acts(css_encoder* e, int T, int B) {
         e->graphs.clear();  // captured pointers are about to change
     }
     if (T > e->cap_tokens) {
-        void* ptrs[] = {e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev};
+        void* ptrs[] = {e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev, e->stats[0], e->stats[1]};
         for (void* p : ptrs)
             if (p) CSS_HIP_TRY(hipFree(p));
         e->cap_tokens = 0;
@@ -226,6 +277,13 @@ int ensure_acts(css_encoder* e, int T, int B) {
         CSS_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * es));
         CSS_HIP_TRY(hipMalloc((void**)&e->ffn, cap * F * es));
         CSS_HIP_TRY(hipMalloc((void**)&e->ids_dev, cap * sizeof(int32_t)));
+        e->stats[0] = e->stats[1] = nullptr;
+        if (c.compute == 0) {
+            for (int i = 0; i < 2; ++i) {
+                CSS_HIP_TRY(hipMalloc((void**)&e->stats[i], cap * 16));
+                CSS_HIP_TRY(hipMemset(e->stats[i], 0, cap * 16));  // slack rows: finite values
+            }
+        }
         e->cap_tokens = (int)cap;
     }
     if (B > e->cap_seqs) {
@@ -240,7 +298,6 @@ int ensure_acts(css_encoder* e, int T, int B) {
     return CSS_OK;
 }
 
-extern int g_gemm_dbg;
 // Tile shapes: 2x2 waves x (2x2) MFMA tiles = 128x128, or 2x4 waves x (4x2) tiles = 256x256
 // (8 waves, 128 KiB ring).  Persistent: one block per CU (grid a multiple of 8).
 template <typename TIn, int EPI, int WM, int WN, int TM, int TN, int NST, int RB, int SPS>
@@ -263,16 +320,31 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
     grid = std::max(8, grid / 8 * 8);
     ProfScope ps(prof, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, (const TIn*)A, (const TIn*)W, bias, C, M, N, K,
-                       qscale_cols, qscale, g_gemm_dbg);
+                       qscale_cols, qscale, enc_env().dbg);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
 
-int g_enc_resid = 2;       // CSS_ENC_RESID: residual stream storage in bf16 mode (see forward_typed)
-int g_gemm_dbg = 0;        // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
-int g_gemm_big_tiles = 1;
-int g_gemm_mfma16 = 1;     // CSS_GEMM_MFMA=32: 32x32x16 MFMA kernel (k_gemm) instead of k_gemm16
-int g_gemm_8phase = 1;     // CSS_GEMM_LOOP=old: the round-1 main loop (k_gemm16) instead of k_gemm8p, for A/B runs
+// k_gemm8p launch (256x256 tiles, persistent, one block per CU); `side` carries the LayerNorm-folding operands
+template <int EPI>
+int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
+                  float qscale, const G8Side& side, int num_cus, hipStream_t st, const char* prof) {
+    CSS_REQUIRE(N % 256 == 0 && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32), "gemm8p: bad shape %d x %d x %d", M, N, K);
+    auto kern = k_gemm8p<EPI>;
+    constexpr size_t lds = 2 * 4 * G8_HT;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);
+    if (rc_ != CSS_OK) return rc_;
+    const int ntiles = (N / 256) * ((M + 255) / 256);
+    int grid = std::min(ntiles, num_cus);
+    grid = std::max(8, grid / 8 * 8);
+    ProfScope ps(prof, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K,
+                       qscale_cols, qscale, side);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
 // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
 
 template <typename TIn, int EPI>
@@ -289,39 +361,23 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* C, int M,
         CSS_LAUNCH_CHECK();
         return CSS_OK;
     }
-    if (g_gemm_big_tiles && M >= 1024 && N % 256 == 0) {
+    const EncEnv& env = enc_env();
+    if (env.big_tiles && M >= 1024 && N % 256 == 0) {
         // ring: 2 stages x 128 B rows.  Rings of 3 / 4 x 64 B rows and 5 x 64 B with two stages per step were
         // measured slower (more barriers, same LDS fill rate) and are not kept.
         if constexpr (sizeof(TIn) == 2 && (EPI == EPI_QKV || EPI == EPI_GELU)) {
-            if (g_gemm_8phase && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32)) {
-                auto kern = k_gemm8p<EPI>;
-                constexpr size_t lds = 2 * 4 * G8_HT;
+            if (env.loop8 && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32))
+                return launch_gemm8p<EPI>(A, W, bias, C, M, N, K, qscale_cols, qscale, G8Side{}, num_cus, st, prof);
+        }
+        if constexpr (sizeof(TIn) == 2) {
+            if (env.mfma16) {  // product mode: the 16x16x32 MFMA variant (CSS_GEMM_MFMA=32 selects k_gemm for A/B runs)
+                CSS_REQUIRE(K % 64 == 0 && K / 64 >= 3, "gemm: K=%d must be a multiple of 64 (>= 192)", K);
+                auto kern = k_gemm16<EPI>;
+                constexpr size_t lds = 2 * 512 * 128;
                 int dev_ = 0;
                 (void)hipGetDevice(&dev_);
                 int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);
                 if (rc_ != CSS_OK) return rc_;
-                const int ntiles = (N / 256) * ((M + 255) / 256);
-                int grid = std::min(ntiles, num_cus);
-                grid = std::max(8, grid / 8 * 8);
-                ProfScope ps(prof, st);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N,
-                                   K, qscale_cols, qscale);
-                CSS_LAUNCH_CHECK();
-                return CSS_OK;
-            }
-        }
-        if constexpr (sizeof(TIn) == 2) {
-            if (g_gemm_mfma16) {  // product mode: the 16x16x32 MFMA variant (CSS_GEMM_MFMA=32 selects k_gemm for A/B runs)
-                CSS_REQUIRE(K % 64 == 0 && K / 64 >= 3, "gemm: K=%d must be a multiple of 64 (>= 192)", K);
-                auto kern = k_gemm16<EPI>;
-                constexpr size_t lds = 2 * 512 * 128;
-                static bool attr_set[64] = {};  // per instantiation and device
-                int dev_ = 0;
-                (void)hipGetDevice(&dev_);
-                if (!attr_set[dev_ & 63]) {
-                    CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_set[dev_ & 63] = true;
-                }
                 const int ntiles = (N / 256) * ((M + 255) / 256);
                 int grid = std::min(ntiles, num_cus);
                 grid = std::max(8, grid / 8 * 8);
@@ -351,9 +407,9 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         CSS_LAUNCH_CHECK();
     }
     const int maxL = c.max_seq_len;
-    // Residual stream storage (bf16 mode): g_enc_resid 0 = fp32 rows (x32) + fp32 branch outputs,
+    // Residual stream storage (bf16 mode): CSS_ENC_RESID 0 = fp32 rows (x32) + fp32 branch outputs,
     // 1 = bf16 residual (the row the next GEMM reads anyway) + fp32 branch outputs, 2 = both bf16.
-    const int rmode = BF ? g_enc_resid : 0;
+    const int rmode = BF ? enc_env().resid : 0;
     // attention-output / FFN2 projection into `pre32` (fp32, or bf16 rows when rmode == 2)
     auto launch_branch_out = [&](const void* a, const void* w, const float* bias, int K, const char* prof) -> int {
         if (rmode == 2) return launch_gemm<TIn, EPI_QKV>(a, w, bias, e->pre32, T, H, K, 0, 1.0f, e->num_cus, st, prof);
@@ -417,6 +473,73 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
     return CSS_OK;
 }
 
+// bf16 product path for batches of >= 1024 tokens: LayerNorm folded into the GEMM epilogues (css_encoder_kernels.h,
+// "LayerNorm without LayerNorm kernels").  Launches per layer: QKV GEMM, attention, O GEMM, FFN1 GEMM, FFN2 GEMM.
+// The two pre tensors alternate between x16 and pre32 (both hold bf16 rows here).
+int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, int T, int max_len, int normalize,
+                        float* out, hipStream_t st) {
+    const css_encoder_cfg& c = e->cfg;
+    const int H = c.hidden, F = c.ffn, maxL = c.max_seq_len;
+    int rc;
+    bf16_t* pre[2] = {(bf16_t*)e->x16, (bf16_t*)e->pre32};
+    {
+        ProfScope ps("enc_embed_ln", st);
+        hipLaunchKernelGGL(k_embed_pre<768>, dim3((T + 3) / 4), dim3(256), 0, st, ids, cu, B, e->wemb, e->pemb, c.vocab,
+                           c.max_pos, pre[0], e->stats[0], T, kStatScale1, kStatScale2);
+        CSS_LAUNCH_CHECK();
+    }
+    const float *g_in = e->embg, *b_in = e->embb;  // the LayerNorm that turns pre[0] into the layer input
+    G8Side side{};
+    side.inv_h = 1.0f / H;
+    side.eps = c.ln_eps;
+    for (int li = 0; li < c.num_layers; ++li) {
+        const LayerW& L = e->layers[li];
+        // x = LN(pre[0]) -> qkv; zeroes stats[1]
+        side.stats_in = e->stats[0];
+        side.stats_out = e->stats[1];
+        if ((rc = launch_gemm8p<EPI_AFF_QKV>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
+                                             side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
+            return rc;
+        {
+            ProfScope ps("enc_attention", st);
+            const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1) * 4;
+            const int nqb = (max_len + 127) / 128;
+            hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st, (const bf16_t*)e->qkv, cu,
+                               e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);
+            CSS_LAUNCH_CHECK();
+        }
+        // pre[1] = ctx Wo^T + (bo + beta) + gamma (pre[0] - mu) rs; stats[1] += row sums
+        side.pprev = pre[0];
+        side.cvec = g_in;
+        if ((rc = launch_gemm8p<EPI_RES>(e->ctx, L.wo_h, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
+            return rc;
+        // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
+        side.stats_in = e->stats[1];
+        side.stats_out = e->stats[0];
+        if ((rc = launch_gemm8p<EPI_AFF_GELU>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
+            return rc;
+        // pre[0] = ffn W2^T + (b2 + beta1) + gamma1 (pre[1] - mu) rs; stats[0] += row sums
+        side.pprev = pre[1];
+        side.cvec = L.ln1g;
+        if ((rc = launch_gemm8p<EPI_RES>(e->ffn, L.w2_h, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
+            return rc;
+        g_in = L.ln2g;
+        b_in = L.ln2b;
+    }
+    {
+        ProfScope ps("enc_pool", st);
+        constexpr int kPoolSlices = 8;
+        // partial sums live in ffn (free after the last FFN2; capacity >= 8 B rows of 8 H bytes): [B][8][H] floats
+        float* part = (float*)e->ffn;
+        hipLaunchKernelGGL(k_pool_partial_ln<768>, dim3(B, kPoolSlices), dim3(256), 0, st, (const bf16_t*)pre[0], e->stats[0], g_in,
+                           b_in, 1.0f / H, c.ln_eps, cu, kPoolSlices, part);
+        hipLaunchKernelGGL(k_pool_final<768>, dim3(B), dim3(256), 0, st, part, cu, kPoolSlices, normalize, out);
+        CSS_LAUNCH_CHECK();
+    }
+    e->x32_valid = false;
+    return CSS_OK;
+}
+
 int forward_any(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, int T, int max_len, int normalize,
                 float* out, hipStream_t st) {
     if (!e->weights_ready) {
@@ -426,6 +549,11 @@ int forward_any(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, in
     CSS_REQUIRE(B >= 1 && T >= B, "css_encoder_forward: bad batch (B=%d, tokens=%d)", B, T);
     CSS_REQUIRE(max_len >= 1 && max_len <= e->cfg.max_seq_len, "css_encoder_forward: max_len=%d outside [1, %d]", max_len,
                 e->cfg.max_seq_len);
+    const EncEnv& env = enc_env();
+    if (e->cfg.compute == 0 && env.fuse_ln && env.big_tiles && env.loop8 && T >= 1024 && e->cfg.ffn % 256 == 0 &&
+        (size_t)T * e->cfg.ffn * 2 < ((size_t)1 << 32))
+        return forward_folded_bf16(e, ids, cu, B, T, max_len, normalize, out, st);
+    e->x32_valid = true;
     return e->cfg.compute == 0 ? forward_typed<bf16_t>(e, ids, cu, B, T, max_len, normalize, out, st)
                                : forward_typed<float>(e, ids, cu, B, T, max_len, normalize, out, st);
 }
@@ -448,11 +576,7 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     int rc = css::check_device(device);
     if (rc != CSS_OK) return rc;
     DeviceGuard g(device);
-    if (const char* t = getenv("CSS_GEMM_TILE")) g_gemm_big_tiles = atoi(t) != 128;
-    if (const char* t = getenv("CSS_GEMM_DBG")) g_gemm_dbg = atoi(t);
-    if (const char* t = getenv("CSS_ENC_RESID")) g_enc_resid = atoi(t);
-    if (const char* t = getenv("CSS_GEMM_MFMA")) g_gemm_mfma16 = atoi(t) != 32;
-    if (const char* t = getenv("CSS_GEMM_LOOP")) g_gemm_8phase = std::string(t) != "old";
+    (void)enc_env();
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;
@@ -492,9 +616,12 @@ int css_encoder_free(css_encoder* e) {
         if (L.wo_h) (void)hipFree(L.wo_h);
         if (L.w1_h) (void)hipFree(L.w1_h);
         if (L.w2_h) (void)hipFree(L.w2_h);
+        void* fp[] = {L.wqkv_f, L.w1_f, L.dqkv, L.d1, L.bo_f, L.b2_f};
+        for (void* p : fp)
+            if (p) (void)hipFree(p);
     }
     void* ptrs[] = {e->bias_tab, e->bucket_dev, e->x32, e->pre32, e->x16, e->qkv, e->ctx, e->ffn, e->ids_dev,
-                    e->cu_dev, e->out_dev};
+                    e->cu_dev, e->out_dev, e->stats[0], e->stats[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -588,7 +715,12 @@ int css_encoder_debug_read(css_encoder* e, const char* what, float* out_host, in
     const bool bf = e->cfg.compute == 0;
     const void* src = nullptr;
     bool typed = true;  // operand-typed (bf16 in product mode) vs always fp32
-    if (w == "x32") { src = e->x32; typed = false; }
+    if (w == "x32") {
+        CSS_REQUIRE(e->x32_valid, "css_encoder_debug_read: the last forward ran the LayerNorm-folded path, which does not "
+                                  "materialise x32 (set CSS_ENC_FUSE_LN=0)");
+        src = e->x32;
+        typed = false;
+    }
     else if (w == "pre32") { src = e->pre32; typed = false; }
     else if (w == "qkv") src = e->qkv;
     else if (w == "ctx") src = e->ctx;

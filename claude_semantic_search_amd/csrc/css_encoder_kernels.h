@@ -98,6 +98,73 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
     }
 }
 
+// LayerNorm-folded path (k_gemm8p EPI_AFF_* / EPI_RES): the embedding sum is stored un-normalised as bf16 together
+// with the row sums of the STORED values in the fixed-point format of row_stats_decode (defined with k_gemm8p).
+template <int H>
+__global__ __launch_bounds__(256) void k_embed_pre(const int32_t* __restrict__ ids, const int32_t* __restrict__ cu,
+                                                   int B, const float* __restrict__ wemb,
+                                                   const float* __restrict__ pemb, int vocab, int max_pos,
+                                                   bf16_t* __restrict__ pre, long long* __restrict__ stats, int T,
+                                                   float scale1, float scale2) {
+    constexpr int NV = H / 256;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    int id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pos = (t - cu[lo]) + 2;
+    pos = pos < max_pos ? pos : max_pos - 1;
+    const float4* w4 = reinterpret_cast<const float4*>(wemb + (size_t)id * H);
+    const float4* p4 = reinterpret_cast<const float4*>(pemb + (size_t)pos * H);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 a = w4[lane + 64 * i], b = p4[lane + 64 * i];
+        ushort4 h;
+        h.x = f2bf(a.x + b.x); h.y = f2bf(a.y + b.y); h.z = f2bf(a.z + b.z); h.w = f2bf(a.w + b.w);
+        reinterpret_cast<ushort4*>(pre + (size_t)t * H)[lane + 64 * i] = h;
+        const float x = bf2f(h.x), y = bf2f(h.y), z = bf2f(h.z), w = bf2f(h.w);
+        s1 += (x + y) + (z + w);
+        s2 += (x * x + y * y) + (z * z + w * w);
+    }
+    s1 = wave_allsum(s1);
+    s2 = wave_allsum(s2);
+    if (lane == 0) {
+        stats[(size_t)t * 2] = __float2ll_rn(s1 * scale1);
+        stats[(size_t)t * 2 + 1] = __float2ll_rn(s2 * scale2);
+    }
+}
+
+// Weight preparation of the LayerNorm-folded path, one wave per output row j of W [N][K]:
+//   Wf[j][k] = bf16(W[j][k] gamma[k] - mean_k(W[j][.] gamma[.])),   d[j] = sum_k beta[k] W[j][k] + bias[j].
+__global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ bias,
+                                                 int N, int K, bf16_t* __restrict__ Wf, float* __restrict__ dvec) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= N) return;
+    float c = 0.f, d = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)j * K + k];
+        c = fmaf(w, gamma[k], c);
+        d = fmaf(beta[k], w, d);
+    }
+    c = wave_allsum(c) / (float)K;
+    d = wave_allsum(d);
+    for (int k = lane; k < K; k += 64) Wf[(size_t)j * K + k] = f2bf(fmaf(W[(size_t)j * K + k], gamma[k], -c));
+    if (lane == 0) dvec[j] = d + bias[j];
+}
+
+__global__ void k_add_vec(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // LayerNorm of token rows: LN(in + resid) (the GEMM epilogue added the bias; the residual add lives
 // here, where the access is perfectly coalesced, so the GEMM epilogue is store-only).  The arithmetic
 // is fp32; TPre / TRes are the storage types of the GEMM output and of the residual stream (float, or
@@ -177,7 +244,9 @@ __global__ __launch_bounds__(256) void k_layernorm(const TPre* __restrict__ in, 
 // ((row>>2)&3): every ds_read_b128 lane group hits 16 distinct slots.  The swizzle is applied
 // on the per-lane SOURCE address of the DMA (its LDS destination is linear) and on reads.
 // k_gemm16 (below) is the product-mode twin of the 256x256 bf16 configuration on 16x16x32 MFMAs.
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2,
+       // k_gemm8p only: LayerNorm folded into the GEMMs (see "LayerNorm without LayerNorm kernels" below)
+       EPI_AFF_QKV = 3, EPI_AFF_GELU = 4, EPI_RES = 5 };
 
 template <typename TIn>
 struct GemmTraits;
@@ -701,17 +770,65 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
 // Measured on MI355X (tools/gemm_lab.hip, same data, one process): 98304 x 2304 x 768: 0.300 vs 0.360 ms for
 // k_gemm16; x 768 x 768: 0.107 vs 0.134; x 768 x 3072: 0.361 vs 0.457.  Requires K % 128 == 0, N % 256 == 0,
 // M * K * 2 < 4 GiB (32-bit source offsets) and >= 256 slack rows behind A and C.
+//
+// LayerNorm without LayerNorm kernels (EPI_AFF_*, EPI_RES).  The post-LN stack is x = LN(pre) with pre = branch
+// output + residual.  The product path never materialises x:
+//   * a GEMM that CONSUMES x (QKV, FFN1) reads the un-normalised pre (bf16) with weights folded at load time
+//     (k_fold_ln): W'[j,k] = W[j,k] gamma[k] - mean_k(W[j,.] gamma), rows centred so that the mean of the token row
+//     drops out (sum_k (pre_k - mu) = 0):   x.W^T + b = rs_t (pre_t . W'_j) + d_j,   d_j = sum_k beta[k] W[j,k] + b_j.
+//     The epilogue is one fma per element from the row's rs (EPI_AFF_*).  (bf16 rounding leaves row sums of W' of
+//     ~1e-3 instead of 0: an error of mu rs 1e-3 per output, below the bf16 resolution of the outputs for any
+//     |mu| of the order of the row's standard deviation.)
+//   * a GEMM that PRODUCES a pre (O projection, FFN2) adds bias' = bias + beta and the rest of the residual
+//     LN(previous pre) = gamma (p rs - mu rs) + beta, recomputed in the accumulator layout from the previous pre
+//     tensor and its row statistics, stores the new pre as bf16 and accumulates the row sums (EPI_RES).
+// Row statistics travel as raw (sum, sum^2) pairs [T][2] in 64-bit FIXED POINT (sum * 2^24, sum^2 * 2^20): each
+// wave adds the sums of its 64 columns (fp32, fixed order) with an integer atomic, so the totals do not depend on
+// the order the waves arrive in and a forward pass stays bit-reproducible.  mu = sum / H, rs = rsqrt(sum^2 / H -
+// mu^2 + eps).  The EPI_AFF_* GEMM of a layer zeroes the statistics the following EPI_RES GEMM accumulates into.
+// Per tile the side data (bias or d row, c row, 256 row-statistic pairs) is DMA'd into LDS one tile ahead.
+constexpr float kStatScale1 = 16777216.f, kStatScale2 = 1048576.f;
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void row_stats_decode(v4u32 raw, float inv_h, float eps, float& rs, float& mrs) {
+    // int64 -> float as hi * 2^32 + lo (two conversions and an fma; the compiler's exact sequence is ~4x longer)
+    const float s1 = fmaf((float)(int)raw[1], 4294967296.f, (float)raw[0]);
+    const float s2 = fmaf((float)(int)raw[3], 4294967296.f, (float)raw[2]);
+    const float mu = s1 * (1.0f / kStatScale1) * inv_h;
+    const float var = fmaf(s2 * (1.0f / kStatScale2), inv_h, -mu * mu);
+    rs = rsqrtf(fmaxf(var, 0.f) + eps);
+    mrs = mu * rs;
+}
+struct G8Side {
+    const long long* stats_in;   // [T][2] raw row sums of the GEMM's input pre (AFF) / of the residual's pre (RES)
+    const float* cvec;       // [N]    RES: gamma of the LayerNorm that makes the residual (its beta is in `bias`)
+    const bf16_t* pprev;     // [T][N] RES: the pre whose LayerNorm is the residual
+    long long* stats_out;    // [T][2] RES: row sums of the pre written by this GEMM; AFF: zeroed for the next EPI_RES GEMM
+    float inv_h;             // 1 / hidden
+    float eps;
+};
+#if defined(G8_EXP) && (G8_EXP & 16)
+#define G8_SIDE_WAVES 2
+#else
+#define G8_SIDE_WAVES 6
+#endif
 constexpr int G8_HT = 16384;
 constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
 
+// `bias`: the bias row (EPI_QKV / EPI_GELU), bias + beta of the residual's LayerNorm (EPI_RES) or the d row (EPI_AFF_*)
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                 const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
-                                                int K, int qscale_cols, float qscale) {
-    static_assert(EPI == EPI_QKV || EPI == EPI_GELU, "bf16 output epilogues");
+                                                int K, int qscale_cols, float qscale, G8Side side) {
+    static_assert(EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_AFF_QKV || EPI == EPI_AFF_GELU || EPI == EPI_RES,
+                  "bf16 output epilogues");
+    constexpr bool AFF = EPI == EPI_AFF_QKV || EPI == EPI_AFF_GELU;
+    constexpr bool RES = EPI == EPI_RES;
+    constexpr bool DO_GELU = EPI == EPI_GELU || EPI == EPI_AFF_GELU;
+    constexpr bool DO_QSCALE = EPI == EPI_QKV || EPI == EPI_AFF_QKV;
     constexpr int NW = 8, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][G8_HT]
-    __shared__ __attribute__((aligned(16))) float sbias[2][BN];
+    // side data of two tiles (parity): [0] bias / d row, [1] gamma row (RES), [2..5] 256 (sum, sum^2) pairs of 16 B
+    __shared__ __attribute__((aligned(16))) float sbias[2][6][BN];
     constexpr int EPI_ROW = 144;
     __shared__ __attribute__((aligned(16))) char sepi[NW][16 * EPI_ROW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -775,23 +892,32 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             }                                                                                                 \
         }                                                                                                     \
     }
-// bias row of tile TI_ -> sbias[TI_ & 1]: 1 KiB = one DMA instruction of wave 0
+// side data of tile TI_ -> sbias[TI_ & 1]: 1-KiB DMA pieces, one per wave (0: bias / d row, 1: gamma row, 2..5: the
+// tile's 256 row-statistic pairs)
 #define G8_BIAS(TI_)                                                                                          \
-    if (wave == 0) {                                                                                          \
+    if (wave < ((AFF || RES) ? G8_SIDE_WAVES : 1) && !((AFF) && wave == 1)) {                                 \
         const int tile_b = xfirst + jx + (TI_) * per_x;                                                       \
+        const float* sp_ = wave == 0 ? bias + (tile_b % ntn) * BN                                             \
+                         : (wave == 1 ? side.cvec + (tile_b % ntn) * BN                                       \
+                                      : reinterpret_cast<const float*>(side.stats_in + (size_t)(tile_b / ntn) * BM * 2) + (wave - 2) * 256);  \
         __builtin_amdgcn_global_load_lds(                                                                     \
-            (const __attribute__((address_space(1))) void*)(bias + (tile_b % ntn) * BN + 4 * lane),           \
-            (__attribute__((address_space(3))) void*)(&sbias[(TI_) & 1][0]), 16, 0, 0);                        \
+            (const __attribute__((address_space(1))) void*)(sp_ + 4 * lane),                                  \
+            (__attribute__((address_space(3))) void*)(&sbias[(TI_) & 1][wave][0]), 16, 0, 0);                  \
     }
 // accumulators := bias row PAR_ (inline-asm LDS reads, see the header comment)
 #define G8_ACC_FROM_BIAS(PAR_)                                                                                \
     {                                                                                                         \
         v4f bv_[4];                                                                                           \
-        const unsigned sboff_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[PAR_][wc * 64 + 4 * lg]; \
+        const unsigned sboff_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[PAR_][0][wc * 64 + 4 * lg]; \
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t" \
                      "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"                                 \
                      : "=&v"(bv_[0]), "=&v"(bv_[1]), "=&v"(bv_[2]), "=&v"(bv_[3]) : "v"(sboff_) : "memory");   \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if constexpr (AFF) { /* zeros, kept opaque so that they are copied with 64-bit moves like the bias */  \
+            bv_[0] = v4f{0.f, 0.f, 0.f, 0.f};                                                                 \
+            asm volatile("" : "+v"(bv_[0]));                                                                  \
+            bv_[1] = bv_[2] = bv_[3] = bv_[0];                                                                \
+        }                                                                                                     \
         _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                         \
             _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[m][n] = bv_[n];                                 \
     }
@@ -857,6 +983,25 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     __builtin_amdgcn_s_barrier();      \
     __builtin_amdgcn_sched_barrier(0);
     int ct_tile = 0, kt = 0;
+// row statistics of the current tile (in LDS since the previous tile's first K step): wave row 0 turns the 256 raw
+// (sum, sum^2) pairs into (rs, mu rs) in place, once per tile, during the tile's second K step; the epilogues of all
+// waves read them many barriers later.  (Inline-asm LDS access: see the header comment.)
+#if defined(G8_EXP) && (G8_EXP & 8)
+#define G8_DO_DECODE 0
+#else
+#define G8_DO_DECODE 1
+#endif
+#define G8_DECODE()                                                                                           \
+    if ((AFF || RES) && kt == 1 && wr == 0 && G8_DO_DECODE) {                                                 \
+        const unsigned so_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[ct_tile & 1][2][(wave * 64 + lane) * 4]; \
+        v4u32 raw_;                                                                                           \
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw_) : "v"(so_) : "memory");      \
+        typedef float v2f_ __attribute__((ext_vector_type(2)));                                               \
+        float rs_, mrs_;                                                                                      \
+        row_stats_decode(raw_, side.inv_h, side.eps, rs_, mrs_);                                              \
+        const v2f_ o_ = {rs_, mrs_};                                                                          \
+        asm volatile("ds_write_b64 %0, %1" : : "v"(so_), "v"(o_) : "memory");                                 \
+    }
 #define G8_KSTEP(D_)                                                                                          \
     {                                                                                                         \
         /* P1 */                                                                                              \
@@ -874,6 +1019,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         G8_MFMA(0, 1, b1)                                                                                     \
         G8_SYNC_B()                                                                                           \
         /* P3 */                                                                                              \
+        G8_DECODE()                                                                                           \
         G8_READ_A(1, D_)                                                                                      \
         G8_ISSUE(G8_B0, D_)                                                                                   \
         G8_SYNC_A()                                                                                           \
@@ -900,24 +1046,135 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             const unsigned wbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + lq * EPI_ROW + 8 * lg);
             const unsigned rbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + (lane >> 3) * EPI_ROW + (lane & 7) * 16);
             bf16_t* cbase = Cout + (size_t)((tile / ntn) * BM + wr * 128 + (lane >> 3)) * N + col0 + (lane & 7) * 8;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
             float sc[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) sc[n] = (EPI == EPI_QKV && col0 + 16 * n < qscale_cols) ? qscale : 1.0f;  // qscale_cols % 16 == 0
+            for (int n = 0; n < 4; ++n) sc[n] = (DO_QSCALE && col0 + 16 * n < qscale_cols) ? qscale : 1.0f;  // qscale_cols % 16 == 0
+            const int par = ct_tile & 1;
+            // AFF: d of this lane's 16 columns, rs of its 8 rows (inline-asm LDS reads: see header); the q scale is folded in
+            v4f dj[4];
+            float rs_m[8], mrs_m[8];
+            if constexpr (AFF) {
+                const unsigned so_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][0][wc * 64 + 4 * lg];
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(dj[0]), "=&v"(dj[1]), "=&v"(dj[2]), "=&v"(dj[3])
+                             : "v"(so_) : "memory");
+            }
+            const unsigned rso_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][2][(wr * 128 + lq) * 4];
+            if constexpr (AFF) {   // (rs, mu rs) of this lane's 8 rows, decoded by G8_DECODE (RES reads them row block by row block)
+                const unsigned ro_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][2][(wr * 128 + lq) * 4];
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f st[8];
+                asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:256\n\tds_read_b64 %2, %8 offset:512\n\t"
+                             "ds_read_b64 %3, %8 offset:768\n\tds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1280\n\t"
+                             "ds_read_b64 %6, %8 offset:1536\n\tds_read_b64 %7, %8 offset:1792\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(st[0]), "=&v"(st[1]), "=&v"(st[2]), "=&v"(st[3]), "=&v"(st[4]), "=&v"(st[5]), "=&v"(st[6]), "=&v"(st[7])
+                             : "v"(ro_) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    rs_m[m] = st[m][0];
+                    mrs_m[m] = st[m][1];
+                }
+            }
+            if constexpr (AFF) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dj[n] *= sc[n];
+                // statistics the next EPI_RES GEMM adds into: zero this tile's rows (first tile column, wave column 0)
+                if (tile % ntn == 0 && wc == 0) {
+                    v4u* zp = reinterpret_cast<v4u*>(side.stats_out + (size_t)((tile / ntn) * BM + wr * 128) * 2);
+                    zp[lane] = v4u{0u, 0u, 0u, 0u};
+                    zp[lane + 64] = v4u{0u, 0u, 0u, 0u};
+                }
+            }
+            // RES: gamma of this lane's 16 columns; the previous pre in whole 128-byte rows (lane: row lane >> 3 (+ 8) of a
+            // 16-row block, 16 bytes at column 8 (lane & 7): every cache line is requested once -- 8-byte pieces at the
+            // accumulator positions hit each line from 4 instructions and ran 10 us per tile slower), all requested before
+            // the first store of the epilogue (a wave's loads return in order behind its stores, whose acknowledgements
+            // take microseconds); each block goes through the wave's LDS scratch into the accumulator layout
+            v4f gj[4];
+            v4u pv[16];
+            const bf16_t* pb = nullptr;
+            float keep[4] = {0.f, 0.f, 0.f, 0.f};   // row sums this lane reports: rows lq + 16 (lg + 4 j), (sum, sum^2)
+            if constexpr (RES) {
+                const unsigned go_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][1][wc * 64 + 4 * lg];
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(gj[0]), "=&v"(gj[1]), "=&v"(gj[2]), "=&v"(gj[3])
+                             : "v"(go_) : "memory");
+                pb = side.pprev + (size_t)((tile / ntn) * BM + wr * 128 + (lane >> 3)) * N + col0 + (lane & 7) * 8;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+#if defined(G8_EXP) && (G8_EXP & 2)
+                    pv[2 * m] = pv[2 * m + 1] = v4u{0u, 0u, 0u, 0u};
+#else
+                    pv[2 * m] = *reinterpret_cast<const v4u*>(pb + (size_t)(16 * m) * N);
+                    pv[2 * m + 1] = *reinterpret_cast<const v4u*>(pb + (size_t)(16 * m + 8) * N);
+#endif
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 uint2 pk[4];
+                v4f s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
+                uint2 pq[4];
+                if constexpr (RES) {
+                    // rows of the previous pre -> accumulator layout; (rs, mu rs) of row lq + 16 m
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    v2f st_;
+                    asm volatile("ds_write_b128 %5, %7\n\tds_write_b128 %5, %8 offset:%9\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_b64 %2, %6 offset:64\n\t"
+                                 "ds_read_b64 %3, %6 offset:96\n\tds_read_b64 %4, %10 offset:%11\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(pq[0]), "=&v"(pq[1]), "=&v"(pq[2]), "=&v"(pq[3]), "=&v"(st_)
+                                 : "v"(rbase), "v"(wbase), "v"(pv[2 * m]), "v"(pv[2 * m + 1]), "n"(8 * EPI_ROW), "v"(rso_), "n"(256 * m)
+                                 : "memory");
+                    rs_m[0] = st_[0];
+                    mrs_m[0] = st_[1];
+                }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     v4f v = acc[m][n];
-                    if constexpr (EPI == EPI_GELU) {
+                    if constexpr (AFF) {
+#if !defined(G8_EXP) || !(G8_EXP & 4)
+                        const float rsn = rs_m[m] * sc[n];
+                        v = __builtin_elementwise_fma(v, v4f{rsn, rsn, rsn, rsn}, dj[n]);
+#endif
+                    }
+                    if constexpr (RES) {
+                        // acc holds branch + bias + beta; residual = gamma (p rs - mu rs) + beta
+                        const uint2 pw = pq[n];
+                        v4f pf;
+                        pf[0] = __uint_as_float(pw.x << 16);
+                        pf[1] = __uint_as_float(pw.x & 0xFFFF0000u);
+                        pf[2] = __uint_as_float(pw.y << 16);
+                        pf[3] = __uint_as_float(pw.y & 0xFFFF0000u);
+                        const v4f u = __builtin_elementwise_fma(pf, v4f{rs_m[0], rs_m[0], rs_m[0], rs_m[0]},
+                                                                v4f{-mrs_m[0], -mrs_m[0], -mrs_m[0], -mrs_m[0]});
+                        v = __builtin_elementwise_fma(gj[n], u, v);
+                        s1v += v;
+                        s2v = __builtin_elementwise_fma(v, v, s2v);
+                    }
+                    if constexpr (DO_GELU) {
                         v = gelu_poly4(v);
-                    } else {
+                    } else if constexpr (DO_QSCALE && !AFF) {
                         v[0] *= sc[n]; v[1] *= sc[n]; v[2] *= sc[n]; v[3] *= sc[n];
                     }
                     pk[n].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
                     pk[n].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
                 }
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                if constexpr (RES) {
+                    // row sums over this wave's 64 columns: 4 values per lane, then the 4 lanes lg = 0..3 of the row
+                    float r1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), r2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
+                    r1 += __shfl_xor(r1, 16);
+                    r2 += __shfl_xor(r2, 16);
+                    r1 += __shfl_xor(r1, 32);
+                    r2 += __shfl_xor(r2, 32);
+                    if (lg == (m & 3)) {
+                        keep[2 * (m >> 2)] = r1;
+                        keep[2 * (m >> 2) + 1] = r2;
+                    }
+                }
                 v4u o0, o1;
                 asm volatile("ds_write_b64 %6, %2\n\tds_write_b64 %6, %3 offset:32\n\tds_write_b64 %6, %4 offset:64\n\t"
                              "ds_write_b64 %6, %5 offset:96\n\ts_waitcnt lgkmcnt(0)\n\t"
@@ -927,6 +1184,19 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                              : "memory");
                 __builtin_nontemporal_store(o0, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m) * N));
                 __builtin_nontemporal_store(o1, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m + 8) * N));
+            }
+            if constexpr (RES) {
+                // every lane reports two rows (fixed-point integer adds: the order of arrival does not matter)
+                unsigned long long* so = reinterpret_cast<unsigned long long*>(side.stats_out) +
+                                         (size_t)((tile / ntn) * BM + wr * 128 + 16 * lg + lq) * 2;
+#if !defined(G8_EXP) || !(G8_EXP & 1)
+                atomicAdd(so, (unsigned long long)__float2ll_rn(keep[0] * kStatScale1));
+                atomicAdd(so + 1, (unsigned long long)__float2ll_rn(keep[1] * kStatScale2));
+                atomicAdd(so + 128, (unsigned long long)__float2ll_rn(keep[2] * kStatScale1));
+                atomicAdd(so + 129, (unsigned long long)__float2ll_rn(keep[3] * kStatScale2));
+#else
+                if (keep[0] + keep[1] + keep[2] + keep[3] == 12345.678f) so[0] = 1;
+#endif
             }
             // bias row of the NEXT tile (in LDS since P2 of this tile's first K step) -> accumulator start values
             G8_ACC_FROM_BIAS((ct_tile + 1) & 1)
@@ -1283,6 +1553,38 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     for (int i = 0; i < PER; ++i) {
         const int c = tid + 256 * i;
         if (c < H) part[((size_t)b * S + sl) * H + c] = acc[i];
+    }
+}
+
+// LayerNorm-folded path: the rows are the last pre tensor (bf16) + its row statistics; the last LayerNorm is applied
+// on the way:  sum_t LN(p_t)[c] = gamma[c] * sum_t (p_t[c] rs_t - mu_t rs_t) + n beta[c].
+template <int H>
+__global__ __launch_bounds__(256) void k_pool_partial_ln(const bf16_t* __restrict__ pre, const long long* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float inv_h, float eps, const int32_t* __restrict__ cu, int S,
+                                                         float* __restrict__ part) {
+    const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    const int per = (L + S - 1) / S;
+    const int lo = min(L, sl * per), hi = min(L, lo + per);
+    constexpr int PER = (H + 255) / 256;
+    float acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+    for (int t = lo; t < hi; ++t) {
+        const v4u32 raw = *reinterpret_cast<const v4u32*>(stats + (size_t)(t0 + t) * 2);
+        float rs, mrs;
+        row_stats_decode(raw, inv_h, eps, rs, mrs);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            if (c < H) acc[i] += fmaf(bf2f(pre[(size_t)(t0 + t) * H + c]), rs, -mrs);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        if (c < H) part[((size_t)b * S + sl) * H + c] = fmaf(acc[i], gamma[c], (float)(hi - lo) * beta[c]);
     }
 }
 

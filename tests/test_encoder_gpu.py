@@ -51,6 +51,33 @@ def test_bf16_mode_matches_oracle_2_layers(lengths):
     assert np.abs(out - ref).max() < 2e-2
 
 
+def test_bf16_folded_layernorm_path_matches_oracle_and_is_bit_reproducible():
+    """Batches of >= 1024 tokens take the path with LayerNorm folded into the GEMM epilogues (no LayerNorm
+    kernels: folded weights + row statistics, css_encoder_kernels.h).  Ragged lengths (row tiles cut sequences,
+    the last tile is partial), 2 layers, against the oracle; the row statistics are accumulated with integer
+    atomics, so two runs must agree bit for bit; the same sequences through the small-batch path (separate
+    LayerNorm kernels) must agree to bf16 rounding noise."""
+    lengths = [384, 1, 200, 383, 77, 129, 300, 256, 2, 45]          # 1777 tokens
+    cfg, batch, ref = _oracle(2, lengths, 7, 13)
+    enc = MpnetEncoder(synthetic_seed=7, compute="bf16", cfg_overrides={"num_layers": 2})
+    out = enc.encode_ids(batch)
+    cos = (out * ref).sum(1)
+    assert cos.min() > 1 - 1e-3, cos
+    assert np.abs(out - ref).max() < 2e-2, np.abs(out - ref).max()
+    again = enc.encode_ids(batch)
+    assert np.array_equal(out, again)
+    with pytest.raises(RuntimeError):
+        enc.debug_read("x32", (sum(lengths), 768))       # not materialised on this path: loud, not stale
+    small = np.concatenate([enc.encode_ids([s]) for s in batch])
+    assert ((small * out).sum(1)).min() > 1 - 5e-5 and np.abs(small - out).max() < 5e-3
+    raw = enc.encode_ids(batch, normalize=False)
+    from oracle import mpnet_oracle as mo
+
+    ref_raw = mo.encode(mo.synth_weights(cfg, 7), cfg, batch, normalize=False)
+    assert np.abs(raw - ref_raw).max() < 3e-2 * np.abs(ref_raw).max()
+    enc.close()
+
+
 def test_full_12_layer_bf16_and_fp32_vs_oracle():
     cfg, batch, ref = _oracle(12, [8, 40, 100, 384, 17, 250], 3, 4)
     for mode, tol in (("fp32", 3e-4), ("bf16", None)):

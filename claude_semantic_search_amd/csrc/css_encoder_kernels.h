@@ -273,38 +273,34 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 }
 
 // GELU without transcendentals (the product GEMM's epilogue is VALU bound: v_rcp / v_exp issue at a quarter of the
-// plain rate and were 40 % of gelu_erf_fast's cycles).  gelu(x) = relu(x) - g(|x|) with g(a) = a Phi(-a), a smooth
-// bump that is 1.5e-5 at a = 4.5 and falls from there; g is a degree-10 minimax-style polynomial (Chebyshev fit,
-// monomials in t = 2a/4.5 - 1) on [0, 4.5], clamped beyond.  |error| <= 1.7e-5 absolute against erf GELU in fp32
-// Horner form (checked over [-8, 8] in 8e-6 steps): below a bf16 half ulp for every |gelu(x)| > 8e-3, and the
-// result is rounded to bf16 right after.
-// Four elements at once so that the four Horner chains interleave (one chain alone is a string of dependent FMAs);
-// |x| clamp and relu on the raw bits (v_and / v_min_u32 / v_max_i32: the float min / max forms carry an extra
-// canonicalising v_max each under IEEE mode).
+// plain rate and were 40 % of gelu_erf_fast's cycles).  gelu(x) = x Phi(x), Phi(x) = 1/2 + x E(x^2) with
+// E(s) = erf(sqrt(s/2)) / (2 sqrt(s)), an entire function of s: a degree-8 polynomial in s on [0, 4.25^2] (weighted
+// minimax fit of s E(s), constrained to E(4.25^2) = 1 / (2 * 4.25) so that Phi(+-4.25) is exactly 1 / 0), evaluated
+// at xc = clamp(x, -4.25, 4.25): beyond the clamp Phi stays 1 / 0, i.e. gelu = x / 0 (|gelu(-4.25)| = 4.5e-5).
+// |error| <= 6e-5 absolute against erf GELU in fp32 Horner form (checked over [-9, 9] in 1e-5 steps; 4.5e-5 of it is
+// the fit), relative error <= 1e-5 for x > 4.25: below a bf16 half ulp for every |gelu(x)| > 0.03, and the result is
+// rounded to bf16 right after.  Per element: one v_med3 + 11 packed-fp32 operations (v_pk_mul / v_pk_fma: two
+// elements per instruction) = 6.5 issue slots; the round-1 form (degree 10 in |x| plus integer clamp / relu, scalar
+// FMAs) took 15 and was 1.3 ms of the 256x384 forward.
 __device__ __forceinline__ v4f gelu_poly4(v4f x) {
-    v4f t, p, r;
+    constexpr float A = 4.25f;
+    v4f xc;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned ab = min(__float_as_uint(x[e]) & 0x7FFFFFFFu, 0x40900000u);   // min(|x|, 4.5) (non-negative floats order like their bits)
-        t[e] = fmaf(__uint_as_float(ab), 0.44444444444f, -1.0f);
-        r[e] = __int_as_float(max(__float_as_int(x[e]), 0));                          // relu(x); -0.0 and NaN payloads aside
-        p[e] = -4.423601382e-02f;
-    }
-#define CSS_GP_STEP(C_) _Pragma("unroll") for (int e = 0; e < 4; ++e) p[e] = fmaf(p[e], t[e], C_);
-    CSS_GP_STEP(2.258405084e-02f)
-    CSS_GP_STEP(1.802777630e-01f)
-    CSS_GP_STEP(-1.780532284e-01f)
-    CSS_GP_STEP(-2.080824415e-01f)
-    CSS_GP_STEP(4.360252249e-01f)
-    CSS_GP_STEP(-2.019351235e-01f)
-    CSS_GP_STEP(-1.475407927e-01f)
-    CSS_GP_STEP(2.464785522e-01f)
-    CSS_GP_STEP(-1.330170564e-01f)
-    CSS_GP_STEP(2.749903583e-02f)
-#undef CSS_GP_STEP
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] -= p[e];
-    return r;
+    for (int e = 0; e < 4; ++e) xc[e] = __builtin_amdgcn_fmed3f(x[e], -A, A);
+    const v4f s = xc * xc;
+#define CSS_GP_C(C_) v4f{C_, C_, C_, C_}
+    v4f p = CSS_GP_C(6.7378984336397e-11f);
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(-6.313554568038171e-09f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(2.6018219045909063e-07f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(-6.285347353696125e-06f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(1.00753313745372e-04f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(-1.1566871544346213e-03f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(9.993435814976692e-03f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(-6.666824966669083e-02f));
+    p = __builtin_elementwise_fma(p, s, CSS_GP_C(3.9911165833473206e-01f));
+    const v4f phi = __builtin_elementwise_fma(xc, p, CSS_GP_C(0.5f));
+#undef CSS_GP_C
+    return x * phi;
 }
 
 // TIn: operand type (bf16_t or float).  Output: EPI_RESID -> fp32 [M,N] = acc + bias (the

@@ -308,13 +308,10 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
     auto kern = k_gemm<TIn, EPI, WM, WN, TM, TN, NST, RB, SPS>;
     const size_t lds = (size_t)NST * (BM + BN) * RB;  // ring of NST stages, RB bytes of K per row
-    static bool attr_set[64] = {};  // per instantiation and device (the attribute belongs to the device's code object)
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    if (!attr_set[dev_ & 63]) {
-        CSS_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_ & 63] = true;
-    }
+    int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);   // (mutex-protected, once per kernel and device)
+    if (rc_ != CSS_OK) return rc_;
     const int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     int grid = std::min(ntn * ntm, num_cus * blocks_per_cu);
     grid = std::max(8, grid / 8 * 8);
@@ -441,7 +438,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
         {
             ProfScope ps("enc_attention", st);
             if constexpr (BF) {
-                const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1) * 4;
+                const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
                 const int nqb = (max_len + 127) / 128;
                 hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st,
                                    (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);
@@ -502,7 +499,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
             return rc;
         {
             ProfScope ps("enc_attention", st);
-            const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1) * 4;
+            const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
             const int nqb = (max_len + 127) / 128;
             hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st, (const bf16_t*)e->qkv, cu,
                                e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);

@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                 // [2][64 keys][128 B]  (swizzled)
     char* Vs = smem + 2 * 8192;      // [2][64 keys][128 B]  (row-major, d contiguous)
-    float* bt = reinterpret_cast<float*>(smem + 4 * 8192);  // [2*maxL-1]
+    float* bt = reinterpret_cast<float*>(smem + 4 * 8192);  // [2*maxL-1] + 64 (padding read by the last, partial tile)
 
     // 1-D grid of B * nqb * heads blocks.  The nqb query blocks of one (sequence, head) read the same K / V rows:
     // they get consecutive slots of ONE XCD (blocks l, l + 8, l + 16, ... share an XCD under round-robin dispatch;
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     const int ld = 3 * hidden;  // row stride of qkv in elements
 
     const float* bsrc = bias_tab + (size_t)head * (2 * maxL - 1);
-    for (int i = tid; i < 2 * maxL - 1; i += 256) bt[i] = bsrc[i];
+    for (int i = tid; i < 2 * maxL - 1 + 64; i += 256) bt[i] = i < 2 * maxL - 1 ? bsrc[i] : 0.f;
 
     // this lane's query (clamped for loads; invalid queries are not stored)
     const int qi = q0 + wave * 32 + fr;
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
-    float mrun = -INFINITY, lrun = 0.f;
+    float mrun = 0.f, lrun = 0.f;   // mrun: reference of the exponentials = running maximum after the first tile
 
     const int nkt = (L + 63) / 64;
     const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
@@ -1386,54 +1386,59 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
         for (int sub = 0; sub < 2; ++sub) {
             const int key0 = kt * 64 + sub * 32;
             if (key0 >= L) break;  // block-uniform
-            // S^T[key][query] = K[key][:] . Q[query][:]
+            // S^T[key][query] = K[key][:] . Q[query][:] + bias - mrun: the accumulator STARTS at bias - mrun (bias from
+            // the LDS table, mrun = this query's running maximum), so the scores come out of the MFMAs already
+            // relative to the reference the exponentials use -- no zeroing, no bias add, no per-score subtraction
+            // afterwards (this kernel is bound by VALU issue slots).  Keys beyond the sequence start at -inf (last,
+            // partial tile only).  Scores are in the log2 domain: q was pre-scaled by log2(e)/8 and bias_tab by
+            // log2(e), so the softmax uses v_exp_f32 (exp2) directly.
             f32x16 s;
+            {
+                const float* bl = bt + (key0 + 4 * fh - qic + (maxL - 1));
+                if (key0 + 32 <= L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                    for (int r = 0; r < 16; ++r) s[r] = bl[(r & 3) + 8 * (r >> 2)] - mrun;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {   // (unconditional reads: the table has 64 entries of padding)
+                        const int ko = (r & 3) + 8 * (r >> 2);
+                        const float bv = bl[ko] - mrun;
+                        s[r] = key0 + 4 * fh + ko < L ? bv : -INFINITY;
+                    }
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), qf[ks], s, 0, 0, 0);
             }
-            // bias (+ key mask on the sequence's last, partial tile only), tile max.
-            // Scores are in the log2 domain: q was pre-scaled by log2(e)/8 and bias_tab by log2(e),
-            // so the softmax uses v_exp_f32 (exp2) directly.
-            float mloc = -INFINITY;
-            if (key0 + 32 <= L) {
+            float mloc = s[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = s[r] + bt[key - qic + (maxL - 1)];
-                    s[r] = v;
-                    mloc = fmaxf(mloc, v);
-                }
-            } else {
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));   // finite: key0 < L means at least one valid key
+            // the reference moves when a score exceeds it (first tiles mostly) and always on the first tile, whose
+            // reference was the arbitrary 0: shift the scores, rescale the running sums
+            const bool first = lrun == 0.f;   // (no tile summed yet: afterwards lrun >= 1, the maximum's own term)
+            if (!__all(mloc <= 0.f && !first)) {
+                const float d = first ? mloc : fmaxf(mloc, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = key < L ? s[r] + bt[key - qic + (maxL - 1)] : -INFINITY;
-                    s[r] = v;
-                    mloc = fmaxf(mloc, v);
-                }
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(mrun, mloc);  // finite: key0 < L means at least one valid key
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[r] - mnew);
-                s[r] = p;
-                lsum += p;
-            }
-            lrun = lrun * alpha + lsum;
-            mrun = mnew;
-            if (!__all(alpha == 1.0f)) {  // the running max moves in the first tiles only
+                for (int r = 0; r < 16; ++r) s[r] -= d;
+                mrun += d;
+                lrun *= alpha;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
             }
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[r]);
+                s[r] = p;
+                lsum += p;
+            }
+            lrun += lsum;
             // O^T[d][query] += V^T[d][key] . P^T[key][query]
 #pragma unroll
             for (int st = 0; st < 2; ++st) {

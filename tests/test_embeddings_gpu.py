@@ -138,7 +138,7 @@ def test_config1_shape_encode_index_search_vs_the_reference_path():
 def test_cross_file_batching_gives_the_per_file_embeddings():
     """generate_embeddings_many / EmbeddingBatcher: 40 'files' of 1..60 chunks through full device batches must give,
     chunk for chunk, what the reference's per-file loop gives (bf16 mode: another batch shape means another GEMM tile
-    walk, so equality is to rounding noise, cos >= 1 - 1e-5), and index + search on both must agree."""
+    walk and kernel path, so equality is to rounding noise, cos >= 1 - 1e-4), and index + search on both must agree."""
     import random
 
     from claude_semantic_search_amd.chunk import Chunk
@@ -159,7 +159,9 @@ def test_cross_file_batching_gives_the_per_file_embeddings():
     total = sum(len(f) for f in files)
     for a, m in zip(per_file, many):
         assert a.shape == m.shape
-        assert ((a * m).sum(1)).min() > 1 - 1e-5 and np.abs(a - m).max() < 5e-3
+        # (per-file batches are small and run the separate-LayerNorm kernels, the merged batches the LayerNorm-folded
+        # GEMM epilogues: other rounding points, each path within 1e-5 of the fp32 oracle -- see test_encoder_gpu.py)
+        assert ((a * m).sum(1)).min() > 1 - 1e-4 and np.abs(a - m).max() < 5e-3
     assert all(isinstance(c.embedding, np.ndarray) and c.embedding.shape == (768,) for f in files for c in f)
     # the batcher made ceil(total / 4096) encode calls instead of 40
     for f, chunks in enumerate(files):

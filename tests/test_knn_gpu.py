@@ -541,3 +541,20 @@ def test_search_right_behind_an_asynchronous_ingest_on_another_stream():
     d1, i1 = ix.search(rows, 1)
     assert i1[:, 0].tolist() == [n - 3, n - 2, n - 1] and np.all(np.abs(d1 - 1.0) < 1e-5)
     ix.close()
+
+
+def test_two_host_threads_search_own_and_shared_indexes(tmp_path):
+    """The concurrency contract of css_hip.h through the C ABI without Python in the way: tests/native/cabi_threads.cc
+    (the driver of the CPU sanitizer builds, tests/test_cabi_sanitizers.py) linked against the product library; two
+    threads each build and search their own index and both search a shared one, 30 rounds, answers must not move."""
+    import subprocess
+    from pathlib import Path
+
+    csrc = Path(__file__).resolve().parents[1] / "claude_semantic_search_amd" / "csrc"
+    r = subprocess.run(["make", "-C", str(csrc), "threads"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(["<s>", "<pad>", "</s>", "<unk>", "fix", "the", "python", "error", "vector", "search",
+                                "kernel", "##s", "on", "a", "gpu", "claude", "session", "index", "test"]) + "\n")
+    r = subprocess.run([str(csrc / "san" / "cabi_threads"), str(vocab), "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "cabi_threads: ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

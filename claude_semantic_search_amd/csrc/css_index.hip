@@ -332,14 +332,25 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
             // a lower bound of the global k-th best: lists only improve, so a stale value only merges more
             const float gk = key2f(__hip_atomic_load(&gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (ls[j * k] < gk) continue;
+            // All blocks finish their rows at about the same time and queue here with the threshold they saw at the
+            // start of the queue.  Every merge raises gthr to the global k-th best, so a waiting block keeps looking
+            // at it and leaves the queue as soon as its own best row can no longer enter the list: ~k ln(blocks)
+            // merges per query instead of one per block (measured on 1 M clustered rows: 12 ms -> under 1 ms per chunk
+            // of 8 flagged queries).
+            int give_up = 0;
             if (lane == 0) {
                 int expect = 0;
                 while (!__hip_atomic_compare_exchange_strong(&fix_lock[q], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT)) {
                     expect = 0;
                     __builtin_amdgcn_s_sleep(8);
+                    if (ls[j * k] < key2f(__hip_atomic_load(&gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        give_up = 1;
+                        break;
+                    }
                 }
             }
+            if (__shfl(give_up, 0)) continue;   // (strictly below the k-th best: ties still merge, lowest ids win)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int i = lane; i < k; i += 64) {

@@ -68,6 +68,37 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
 //   16x16x32: lane (lq = lane & 15, lg = lane >> 4): query 16 m + lq, register r = row 4 lg + r of row tile n
 #define CZ_QOFF(M_) (MS * (M_) + lq)
 #define CZ_ROFF(N_, R_) (MS == 32 ? 32 * (N_) + ((R_) & 3) + 8 * ((R_) >> 2) + 4 * lg : 16 * (N_) + 4 * lg + (R_))
+// Wave-local hit list of k_scan_coarse8 (CZ_STAGED kernels): [score | row | query] arrays of CZ_WCAP entries per wave.
+// CZ_FLUSH: every lane takes entries lane, lane + 64, ...: one returning atomic per entry, all of a pass in flight
+// together.  (Inline-asm LDS access: compiler-visible LDS traffic next to the pending LDS-DMA of the ring costs a
+// vmcnt(0), css_encoder_kernels.h.)
+constexpr int CZ_WCAP = 256;
+// OR of v over the 64 lanes (DPP: four shifts inside the 16-lane rows, then the row totals travel to the last lane)
+__device__ __forceinline__ unsigned cz_wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#define CZ_FLUSH()                                                                                                     \
+    {                                                                                                                  \
+        for (int i_ = lane; i_ < wcount; i_ += 64) {                                                                   \
+            float fs_;                                                                                                 \
+            unsigned fr_, fq_;                                                                                         \
+            const unsigned fa_ = wl_base + (unsigned)i_ * 4u;                                                          \
+            asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:%4\n\tds_read_b32 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)" \
+                         : "=&v"(fs_), "=&v"(fr_), "=&v"(fq_) : "v"(fa_), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
+            const int slot_ = atomicAdd(&cand_n[fq_], 1);                                                              \
+            if (slot_ < CZ_CAP) {                                                                                      \
+                cand_s[(size_t)fq_ * CZ_CAP + slot_] = fs_;                                                            \
+                cand_i[(size_t)fq_ * CZ_CAP + slot_] = fr_;                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+        wcount = 0;                                                                                                    \
+    }
 #define CZ_EPILOGUE()                                                                                        \
             const int64_t tile = CZ_TILE_OF(ct_tile);                                                                  \
             const int64_t row0 = tile * CZ_T + wc * 64;                                                                \
@@ -101,9 +132,12 @@ _Pragma("unroll")                                                               
                         }                                                                                              \
                 }                                                                                                      \
             } else {                                                                                                   \
-                /* per 16-query tile m: one wave-wide vote over its TN * NR scores; only tiles with a hit walk their     \
-                   scores lane by lane (a vote over all 128 scores made ~90 % of the block tiles at 10 M rows pay a       \
-                   128-branch walk in some wave: 2.5 us per tile once the main loop no longer hid it) */                  \
+                /* One wave-wide vote per query tile m keeps the usual case -- no hit -- at a compare per score.  A tile m  \
+                   with hits builds each lane's bit mask of its TN * NR scores that reach the threshold (and lie inside    \
+                   the index / the allow bitmap) and hands the hits on.  (Until round 2 every hit made its own returning   \
+                   atomic, each waited for in turn: ~0.7 us per hit and wave, 100 us per tile in the early stages of the    \
+                   cascade, whose thresholds are loose, and 2 us per tile in the main stage.) */                            \
+                unsigned anym = 0u;                                                                                    \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
                     const float thr_q = sthr[wr * 128 + CZ_QOFF(m)];                                                   \
@@ -112,24 +146,110 @@ _Pragma("unroll")                                                               
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
                         for (int r = 0; r < NR; ++r) any |= acc[m][n][r] >= thr_q;                                     \
-                    if (__ballot(any) != 0ull) {                                                                       \
-                        const int q = qtile * CZ_T + wr * 128 + CZ_QOFF(m);                                            \
+                    anym |= __ballot(any) != 0ull ? 1u << m : 0u;                                                      \
+                }                                                                                                      \
+                if (anym != 0u && !(dbg & 2)) {   /* dbg bit1 (timing experiments): votes only, no appends */           \
+                    const bool edge = row0 + 64 > ntotal || mask != nullptr;   /* wave uniform */                      \
+                    if constexpr (CZ_STAGED) {                                                                         \
+                        /* k_scan_coarse8 (16x16 tiles: TM = 8, TN = 4, NR = 4).  The 8 waves of a block and the blocks     \
+                           that share its row tiles move in lockstep, so a tile costs what its SLOWEST wave spends here:    \
+                           the work per hit has to be small, not only the work per tile.  A query tile m with a hit builds   \
+                           each lane's 16-bit mask, ORs it over the wave, and a run-time loop visits only the score           \
+                           positions that hold a hit somewhere in the wave (one or two); the score comes out of the           \
+                           accumulator registers through a 16-way switch.  Hits go to this wave's LDS list (slot = wave       \
+                           count + rank of the lane among the hits of the position), which is written to the candidate        \
+                           buffers when it is nearly full and at the end of the kernel (CZ_FLUSH): no atomic round trip in    \
+                           the tile loop. */                                                                                  \
+_Pragma("unroll")                                                                                                      \
+                        for (int m = 0; m < TM; ++m) {                                                                 \
+                            if (((anym >> m) & 1u) == 0u) continue;   /* wave uniform */                               \
+                            const float thr_q = sthr[wr * 128 + MS * m + lq];                                          \
+                            unsigned h = 0u;                                                                           \
+_Pragma("unroll")                                                                                                      \
+                            for (int n = 0; n < TN; ++n)                                                               \
+_Pragma("unroll")                                                                                                      \
+                                for (int r = 0; r < NR; ++r) h |= (acc[m][n][r] >= thr_q ? 1u : 0u) << (n * NR + r);   \
+                            unsigned ho = cz_wave_or(h);                                                               \
+                            const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + MS * m + lq);                     \
+_Pragma("nounroll")                                                                                                    \
+                            while (ho != 0u) {                                                                         \
+                                const int bit = __builtin_ctz(ho);                                                     \
+                                ho &= ho - 1u;                                                                         \
+                                float v_;                                                                              \
+                                switch (bit) {                                                                         \
+                                    default: v_ = acc[m][0][0]; break;                                                 \
+                                    case 1: v_ = acc[m][0][1]; break;                                                  \
+                                    case 2: v_ = acc[m][0][2]; break;                                                  \
+                                    case 3: v_ = acc[m][0][3]; break;                                                  \
+                                    case 4: v_ = acc[m][1][0]; break;                                                  \
+                                    case 5: v_ = acc[m][1][1]; break;                                                  \
+                                    case 6: v_ = acc[m][1][2]; break;                                                  \
+                                    case 7: v_ = acc[m][1][3]; break;                                                  \
+                                    case 8: v_ = acc[m][2][0]; break;                                                  \
+                                    case 9: v_ = acc[m][2][1]; break;                                                  \
+                                    case 10: v_ = acc[m][2][2]; break;                                                 \
+                                    case 11: v_ = acc[m][2][3]; break;                                                 \
+                                    case 12: v_ = acc[m][3][0]; break;                                                 \
+                                    case 13: v_ = acc[m][3][1]; break;                                                 \
+                                    case 14: v_ = acc[m][3][2]; break;                                                 \
+                                    case 15: v_ = acc[m][3][3]; break;                                                 \
+                                }                                                                                      \
+                                const int64_t row = row0 + 16 * (bit >> 2) + 4 * lg + (bit & 3);                       \
+                                bool hit = (h >> bit) & 1u;                                                            \
+                                if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);                          \
+                                const unsigned long long b = __ballot(hit);                                            \
+                                if (b == 0ull) continue;                                                               \
+                                if (wcount + 64 > CZ_WCAP) {                                                           \
+                                    CZ_FLUSH();                                                                        \
+                                }                                                                                      \
+                                if (hit) {                                                                             \
+                                    const unsigned sl = (unsigned)wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u)); \
+                                    const unsigned ad = wl_base + sl * 4u;                                             \
+                                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5" \
+                                                 : : "v"(ad), "v"(v_), "v"((unsigned)row), "v"(qv), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
+                                }                                                                                      \
+                                wcount += __popcll(b);                                                                 \
+                            }                                                                                          \
+                        }                                                                                              \
+                    } else {                                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int m = 0; m < TM; ++m) {                                                                     \
+                        if (((anym >> m) & 1u) == 0u) continue;   /* wave uniform */                                   \
+                        const float thr_q = sthr[wr * 128 + CZ_QOFF(m)];                                               \
+                        unsigned h = 0u;                                                                               \
 _Pragma("unroll")                                                                                                      \
                         for (int n = 0; n < TN; ++n)                                                                   \
 _Pragma("unroll")                                                                                                      \
-                            for (int r = 0; r < NR; ++r) {                                                             \
-                                const float v = acc[m][n][r];                                                          \
-                                if (v >= thr_q) {                                                                      \
+                            for (int r = 0; r < NR; ++r) h |= (acc[m][n][r] >= thr_q ? 1u : 0u) << (n * NR + r);       \
+                        if (edge && h != 0u) {                                                                         \
+_Pragma("unroll")                                                                                                      \
+                            for (int n = 0; n < TN; ++n)                                                               \
+_Pragma("unroll")                                                                                                      \
+                                for (int r = 0; r < NR; ++r) {                                                         \
                                     const int64_t row = row0 + CZ_ROFF(n, r);                                          \
-                                    if (row < ntotal && CZ_ALLOWED(mask, row)) {                                       \
-                                        const int slot = atomicAdd(&cand_n[q], 1);                                     \
+                                    if (((h >> (n * NR + r)) & 1u) && !(row < ntotal && CZ_ALLOWED(mask, row)))        \
+                                        h &= ~(1u << (n * NR + r));                                                    \
+                                }                                                                                      \
+                        }                                                                                              \
+                        if (h != 0u) {                                                                                 \
+                            /* one returning atomic per lane and query tile reserves the slots of all its hits */      \
+                            const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + CZ_QOFF(m));                      \
+                            int slot = atomicAdd(&cand_n[qv], __popc(h));                                              \
+                            const size_t qb = (size_t)qv * CZ_CAP;                                                     \
+_Pragma("unroll")                                                                                                      \
+                            for (int n = 0; n < TN; ++n)                                                               \
+_Pragma("unroll")                                                                                                      \
+                                for (int r = 0; r < NR; ++r) {                                                         \
+                                    if ((h >> (n * NR + r)) & 1u) {                                                    \
                                         if (slot < CZ_CAP) {                                                           \
-                                            cand_s[(size_t)q * CZ_CAP + slot] = v;                                     \
-                                            cand_i[(size_t)q * CZ_CAP + slot] = (uint32_t)row;                         \
+                                            cand_s[qb + slot] = acc[m][n][r];                                          \
+                                            cand_i[qb + slot] = (uint32_t)(row0 + CZ_ROFF(n, r));                      \
                                         }                                                                              \
+                                        ++slot;                                                                        \
                                     }                                                                                  \
                                 }                                                                                      \
-                            }                                                                                          \
+                        }                                                                                              \
+                    }                                                                                                  \
                     }                                                                                                  \
                 }                                                                                                      \
             }                                                                                                          \
@@ -186,6 +306,11 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
     __shared__ float sthr[CZ_T];
     if (tid < CZ_T) sthr[tid] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
     __syncthreads();
+    constexpr bool CZ_STAGED = false;   // hits are appended straight from the epilogue (see k_scan_coarse8)
+    int wcount = 0;
+    const unsigned wl_base = 0u;
+    (void)wcount;
+    (void)wl_base;
 
     // Sibling pacing (speed only, never needed for correctness): the nqt blocks that walk the same row tiles
     // drift apart (appends, DMA jitter); once they are more than ~2 K-steps apart the tile's rows have left
@@ -426,8 +551,12 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
 
     __shared__ float sthr[CZ_T];
     __shared__ int space[4];   // landing word of the sibling-pacing counter read
+    __shared__ float wl[8][3][CZ_WCAP];   // per-wave hit lists: [score | row | query] (CZ_FLUSH)
     if (tid < CZ_T) sthr[tid] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
     __syncthreads();
+    constexpr bool CZ_STAGED = !STAGE0;
+    int wcount = 0;                       // entries in this wave's list (wave uniform)
+    const unsigned wl_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&wl[wave][0][0];
 
     int* my_cnt = pace_cnt ? pace_cnt + xcd * slots + jx / nqt : nullptr;
     bool pace = my_cnt != nullptr && nqt > 1 && KT >= 4 && wave == 0;
@@ -629,6 +758,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
+    if constexpr (CZ_STAGED) {
+        if (wcount > 0) CZ_FLUSH();
+    }
 #undef C8_KSTEP
 #undef C8_PACE
 #undef C8_SYNC_A

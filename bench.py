@@ -319,9 +319,50 @@ def bench_encoder(args, dev, log):
                             "host_threads": os.cpu_count(), "includes": "utf-8 encode, tokenise, H2D ids, forward, D2H"}
         log(f"encoder text path: {ntext / t_all:.0f} chunks/s end to end ({type(enc.tokenizer).__name__}, "
             f"{t_tok / ntext * 256 * 1e3:.1f} ms tokenisation per 256 texts)")
+        # ---- file-size mix: the reference embeds one conversation file at a time
+        # (src/cli.py:120-169), i.e. ragged batches; EmbeddingGenerator.generate_embeddings_many / EmbeddingBatcher
+        # carry the chunks of many files through full device batches.  Same texts, same generator, both ways.
+        from claude_semantic_search_amd.chunk import Chunk
+        from claude_semantic_search_amd.embeddings import EmbeddingConfig, EmbeddingGenerator
+
+        enc.close()
+        enc = None
+        gen = EmbeddingGenerator(EmbeddingConfig(synthetic_weights_seed=1, batch_size=B, show_progress=False,
+                                                 embeddings_as_arrays=True, use_gpu=True, auto_batch_size=False))
+        gen.load_model()
+        gen.model.tokenizer = make_wordpiece(os.path.join(vdir, "vocab.txt"))
+        files, i = [], 0
+        while i < ntext:
+            r = rng.random()
+            n = rng.randint(1, 6) if r < 0.55 else (rng.randint(8, 40) if r < 0.9 else rng.randint(60, 300))
+            n = min(n, ntext - i)
+            files.append([Chunk(f"c{i + j}", texts[i + j], {}) for j in range(n)])
+            i += n
+        gen.generate_embeddings(files[-1])          # warm-up of both shapes
+        gen.generate_embeddings_many(files[:8])
+        t0 = time.perf_counter()
+        for f in files:
+            gen.generate_embeddings(f)
+        t_files = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gen.generate_embeddings_many(files)
+        t_many = time.perf_counter() - t0
+        sizes = sorted(len(f) for f in files)
+        res["file_mix"] = {"files": len(files), "chunks": ntext, "chunks_per_file_median": sizes[len(sizes) // 2],
+                           "chunks_per_file_max": sizes[-1],
+                           "per_file_loop_chunks_per_s": ntext / t_files, "cross_file_batches_chunks_per_s": ntext / t_many,
+                           "speedup": t_files / t_many,
+                           "note": "per_file_loop = the reference's src/cli.py:120-169 call pattern (generate_embeddings per "
+                                   "file); cross_file = EmbeddingGenerator.generate_embeddings_many (EmbeddingBatcher)"}
+        log(f"file mix ({len(files)} files, median {sizes[len(sizes) // 2]} chunks): per-file loop {ntext / t_files:.0f} chunks/s, "
+            f"cross-file batches {ntext / t_many:.0f} chunks/s")
+        if hasattr(gen.model, "close"):
+            gen.model.close()
     except Exception as ex:  # the text path is an extra: never fail the bench line over it
-        res["text_path"] = {"error": repr(ex)}
-    enc.close()
+        res.setdefault("text_path", {"error": repr(ex)})
+        res.setdefault("file_mix", {"error": repr(ex)})
+    if enc is not None:
+        enc.close()
     return res
 
 

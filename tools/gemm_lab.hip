@@ -23,6 +23,14 @@
 typedef unsigned short bf16_t;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+// -DLAB_F16: the same loops on fp16 operands (v_mfma_f32_16x16x32_f16): clock / power comparison with bf16
+#ifdef LAB_F16
+typedef _Float16 v8in __attribute__((ext_vector_type(8)));
+#define LAB_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 v8in __attribute__((ext_vector_type(8)));
+#define LAB_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
 
 #define HIP_OK(x)                                                                              \
     do {                                                                                       \
@@ -137,8 +145,8 @@ __global__ __launch_bounds__(512) void k_gemm_v0(const bf16_t* __restrict__ A, c
             for (int m = 0; m < TM; ++m)
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, b[n]),
-                                                                        __builtin_bit_cast(v8bf, a[m]), acc[m][n], 0, 0, 0);
+                    acc[m][n] = LAB_MFMA(__builtin_bit_cast(v8in, b[n]),
+                                                                        __builtin_bit_cast(v8in, a[m]), acc[m][n], 0, 0, 0);
         }
         if (++kt == KT) {
             const int tile = xfirst + jx + ct_tile * per_x;
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                 \
-                    acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
-                        __builtin_bit_cast(v8bf, B_[n][c]), __builtin_bit_cast(v8bf, a[j][c]),                \
+                    acc[4 * (MH_) + j][2 * (NH_) + n] = LAB_MFMA(              \
+                        __builtin_bit_cast(v8in, B_[n][c]), __builtin_bit_cast(v8in, a[j][c]),                \
                         acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                          \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }
@@ -377,16 +385,16 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
         __builtin_amdgcn_s_setprio(1);                                                                        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
             _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
-                acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-                    __builtin_bit_cast(v8bf, B_[n][0]), __builtin_bit_cast(v8bf, a[j][0]),                    \
+                acc[4 * (MH_) + j][2 * (NH_) + n] = LAB_MFMA(                  \
+                    __builtin_bit_cast(v8in, B_[n][0]), __builtin_bit_cast(v8in, a[j][0]),                    \
                     acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         V1_ISSUE(KIND_, DB_)                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
             _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
-                acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-                    __builtin_bit_cast(v8bf, B_[n][1]), __builtin_bit_cast(v8bf, a[j][1]),                    \
+                acc[4 * (MH_) + j][2 * (NH_) + n] = LAB_MFMA(                  \
+                    __builtin_bit_cast(v8in, B_[n][1]), __builtin_bit_cast(v8in, a[j][1]),                    \
                     acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                              \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }
@@ -564,6 +572,13 @@ static inline bf16_t f2bf_host(float f) {
     return (bf16_t)u;
 }
 
+#ifdef LAB_F16
+static inline bf16_t f2in_host(float f) { _Float16 h = (_Float16)f; bf16_t u; memcpy(&u, &h, 2); return u; }
+static inline float in2f_host(bf16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+#else
+#define f2in_host f2bf_host
+#define in2f_host bf2f_host
+#endif
 int main(int argc, char** argv) {
     int M = argc > 1 ? atoi(argv[1]) : 98304, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
     int mask = argc > 4 ? atoi(argv[4]) : 7, reps = argc > 5 ? atoi(argv[5]) : 20;
@@ -580,8 +595,8 @@ int main(int argc, char** argv) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         return (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0);
     };
-    for (auto& v : hA) v = f2bf_host(rnd());
-    for (auto& v : hW) v = f2bf_host(rnd() * 0.05f);
+    for (auto& v : hA) v = f2in_host(rnd());
+    for (auto& v : hW) v = f2in_host(rnd() * 0.05f);
     for (auto& v : hb) v = rnd();
     bf16_t *dA, *dW, *dC;
     float* db;
@@ -633,7 +648,7 @@ int main(int argc, char** argv) {
                 cc = (j % 256) * (N / 256);
             }
             double ref = hb[cc];
-            for (int k2 = 0; k2 < K; ++k2) ref += (double)bf2f_host(hA[(size_t)rr * K + k2]) * bf2f_host(hW[(size_t)cc * K + k2]);
+            for (int k2 = 0; k2 < K; ++k2) ref += (double)in2f_host(hA[(size_t)rr * K + k2]) * in2f_host(hW[(size_t)cc * K + k2]);
             const double got = bf2f_host(hC[(size_t)rr * N + cc]);
             const double err = fabs(got - ref);
             if (err > maxerr) maxerr = err;

@@ -31,6 +31,13 @@ timeout -k 10 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT
     -d $O/pmc_b -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --enc-steps 2 > $O/pmc_b.json 2> $O/pmc_b.err || exit 8
 python3 tools/pmc_counters.py $O/pmc_counters.json $O/pmc_a $O/pmc_b \
   --note "rocprofv3 --pmc (two separate passes) on python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --enc-steps 2" > $O/pmc_counters.txt
+# the same two counter passes over the encoder alone at its fixed 256 x 384 shape (every launch full size)
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+    -d $O/pmc_a_enc -o run --output-format csv -- python3 bench.py --only-encoder --enc-fixed-only --no-cpu-baseline --enc-steps 3 > $O/pmc_a_enc.json 2> $O/pmc_a_enc.err || exit 9
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
+    -d $O/pmc_b_enc -o run --output-format csv -- python3 bench.py --only-encoder --enc-fixed-only --no-cpu-baseline --enc-steps 3 > $O/pmc_b_enc.json 2> $O/pmc_b_enc.err || exit 10
+python3 tools/pmc_counters.py $O/pmc_counters_encoder.json $O/pmc_a_enc $O/pmc_b_enc \
+  --note "rocprofv3 --pmc (two separate passes) on python3 bench.py --only-encoder --enc-fixed-only --no-cpu-baseline --enc-steps 3" > $O/pmc_counters_encoder.txt
 find $O -name "*kernel_trace.csv" -delete   # large; the stats csv is the committed summary
 find $O -name "*counter_collection.csv" -size +20M -delete
 ls -la $O $O/stats

@@ -133,7 +133,7 @@ def pmc_traffic(kernel_prefix, workload):
 
 def pmc_traffic_encoder(workload):
     """HBM-side bytes of ONE encoder forward: every kernel's bytes summed over a profiled run of the fixed shape
-    (profiles/r*_pmc_hbm_traffic_encoder.json), divided by the number of forwards (= launches of k_embed_ln)."""
+    (profiles/r*_pmc_hbm_traffic_encoder.json), divided by the number of forwards (= launches of the embedding kernel)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_encoder.json")), reverse=True):
         try:
@@ -143,11 +143,11 @@ def pmc_traffic_encoder(workload):
         if d.get("workload") != workload:
             continue
         ks = d.get("kernels", {})
-        fw = sum(v["launches"] for k_, v in ks.items() if k_.startswith("k_embed_ln"))
+        fw = sum(v["launches"] for k_, v in ks.items() if k_.startswith(("k_embed_ln", "k_embed_pre")))
         if not fw:
             continue
         tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k_, v in ks.items()
-                  if k_.startswith(("k_gemm", "k_attention", "k_layernorm", "k_embed_ln", "k_pool")))
+                  if k_.startswith(("k_gemm", "k_attention", "k_layernorm", "k_embed", "k_pool")))
         return {"bytes_per_forward": tot / fw, "source": os.path.relpath(f, ROOT)}
     return None
 

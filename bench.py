@@ -42,6 +42,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 CASCADE_GROWTH = 8 if os.environ.get("CSS_KNN_GROWTH") == "8" else 4   # growth factor of the coarse cascade (css_index.hip)
+SWEEP_GROWTH = int(os.environ.get("CSS_KNN_GROWTH_SWEEP", "4"))         # ... of the 1..4-query sweep cascade
+if SWEEP_GROWTH not in (4, 8, 16):
+    SWEEP_GROWTH = 4
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3    # dense fp32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak
@@ -533,9 +536,9 @@ def main():
             dt = (time.perf_counter() - t0) / reps
             nat.prof_enable(False)
             ms, n = nat.prof_read("knn_sweep_coarse_main")
-            if n:   # coarse sweep over the bf16 shadow rows: main stage = the row tiles t with t % 4 != 0
+            if n:   # coarse sweep over the bf16 shadow rows: main stage = the row tiles t with t % g != 0 (g = 4)
                 ntiles = -(-shard // 256)
-                main_rows = min(((ntiles - 1) - (ntiles - 1) // CASCADE_GROWTH) * 256, shard)
+                main_rows = min(((ntiles - 1) - (ntiles - 1) // SWEEP_GROWTH) * 256, shard)
                 kbytes = main_rows * args.dim * 2
                 kname = "k_sweep_coarse<1, 6, true>"
             else:   # fp32 sweep (no shadow rows)

@@ -1231,7 +1231,8 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 // ---- environment switches (experiments and verification): read once, never written afterwards
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
-    int growth = 4;       // CSS_KNN_GROWTH=8: growth factor of the nested row sample
+    int growth = 4;       // CSS_KNN_GROWTH=8: growth factor of the nested row sample (batched MFMA cascade)
+    int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
@@ -1242,6 +1243,10 @@ const KnnEnv& knn_env() {
         KnnEnv e;
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
         if (const char* m = getenv("CSS_KNN_GROWTH")) e.growth = atoi(m) == 8 ? 8 : 4;
+        if (const char* m = getenv("CSS_KNN_GROWTH_SWEEP")) {
+            const int v = atoi(m);
+            e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 4;
+        }
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
@@ -1550,16 +1555,32 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     int* nflag = ix->cflags + 2 * nq_pad;
     ix->last_nflag = nflag;
 
-    // cascade schedule: stage 0 reads every s0-th row tile (2..7 tiles), then strides s0/4 ... 1
+    // cascade schedule: a nested, uniformly strided sample of row tiles.  Stage 0 reads every s-th tile (at most 15
+    // tiles: it keeps every score, 3840 of the 4096 slots), every later stage the tiles at a stride `ratio` times
+    // smaller that were not read before; the last stage has stride 1.
+    // Growth factor g: every stage reads g-1 times the tiles read before it.  Batches (MFMA scan): g = 4 -- the last
+    // stage is 3/4 of the rows and appends ~3k + band candidates per query; g = 8 measured 2 % slower (more appends in
+    // the lockstep epilogue of the main stage).  1..4 queries (sweep): also g = 4.  Fewer, larger stages do not help
+    // there -- measured at 10 M rows, k = 10: g = 4 / 8 / 16 (7 / 5 / 4 stages) all take 2.71-2.72 ms, the call is the
+    // 15.36 GB of shadow rows at the sweep's bandwidth plus ~0.25 ms -- and with k = 100 (the reference's call shape)
+    // g = 16 overflows the 4096-slot buffers (~k g candidates per stage) and lands in the exact fix-up: 10 ms.
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
-    int64_t s0 = 1;
-    // growth factor g of the nested sample: every stage reads g-1 times the tiles read before it.  g = 4: the last
-    // stage is 3/4 of the rows and appends ~3k + band candidates per query.  g = 8 (CSS_KNN_GROWTH=8; stage 0 then
-    // holds up to 15 tiles = 3840 rows per query, still inside the 4096-slot buffer) measured 2 % slower for batches
-    // (more appends in the main stage) and the same for single queries.
-    const int g = env.growth;
-    while (ntiles / (s0 * g) >= 2) s0 *= g;
-    const int64_t n0 = (ntiles + s0 - 1) / s0;
+    const int g = sweep ? env.growth_sweep : env.growth;
+    struct Stage {
+        int64_t stride;
+        int ratio;   // stride of the previous stage / this stride (stage 0: unused)
+    };
+    std::vector<Stage> sched;
+    {
+        int64_t s0 = 1;
+        while (ntiles / (s0 * g) >= 2) s0 *= g;
+        const int64_t w0 = (ntiles + s0 - 1) / s0;          // 2 .. 2g-1 tiles at stride s0
+        const int g0 = (int)((w0 + 14) / 15);                // > 1: one coarser first stage in front
+        if (g0 > 1) sched.push_back({s0 * g0, 0});
+        sched.push_back({s0, g0});
+        for (int64_t s = s0 / g; s >= 1; s /= g) sched.push_back({s, g});
+    }
+    const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
 
     {
         if (!sweep) {
@@ -1602,22 +1623,24 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     int stage_idx = 0;
     {
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
-    for (int64_t s = s0;; s /= g) {
-        const bool stage0 = s == s0;
+    for (size_t si = 0; si < sched.size(); ++si) {
+        const int64_t s = sched[si].stride;
+        const int gr = si == 0 ? g : sched[si].ratio;   // (stage 0 does not use the ratio)
+        const bool stage0 = si == 0;
         const int64_t W = (ntiles + s - 1) / s;
-        const int64_t count = stage0 ? W : (W - 1) - (W - 1) / g;
+        const int64_t count = stage0 ? W : (W - 1) - (W - 1) / gr;
         if (count > 0 && sweep) {
             ProfScope ps(s == 1 && !stage0 ? "knn_sweep_coarse_main" : "knn_sweep_coarse_stage", st);
-            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, g - 1, stage0, st);
-            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, g - 1, stage0, st);
-            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, g - 1, stage0, st);
+            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, gr - 1, stage0, st);
+            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, gr - 1, stage0, st);
+            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, gr - 1, stage0, st);
             if (rc != CSS_OK) return rc;
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, g - 1, pace, ix->cur_mask, xn2, env.dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;

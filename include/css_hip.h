@@ -181,7 +181,10 @@ int css_encoder_init_synthetic(css_encoder* enc, uint64_t seed);
 int css_encoder_export_weight(const css_encoder* enc, const char* name, float* out_host, int64_t numel);
 /* Packed var-len batch: input_ids[cu_seqlens[B]] tokens, sequence b occupies
  * [cu_seqlens[b], cu_seqlens[b+1]); every length in [1, max_seq_len].
- * out: [B, hidden] fp32 = masked mean-pool (+ L2 normalise when normalize != 0). */
+ * out: [B, hidden] fp32 = masked mean-pool (+ L2 normalise when normalize != 0).
+ * The same batch gives the same bits on every run (row statistics of the folded
+ * LayerNorm are accumulated with integer atomics); another batch composition may take
+ * another kernel path (GEMM tile walk, folded / separate LayerNorm): bf16 rounding noise. */
 int css_encoder_forward(css_encoder* enc, const int32_t* input_ids_host, const int32_t* cu_seqlens_host,
                         int B, int normalize, float* out_host);
 int css_encoder_forward_dev(css_encoder* enc, const int32_t* input_ids_dev, const int32_t* cu_seqlens_dev,
@@ -189,7 +192,10 @@ int css_encoder_forward_dev(css_encoder* enc, const int32_t* input_ids_dev, cons
 
 /* Test/diagnostic hook: copy an activation buffer of the LAST forward back to the
  * host as fp32 ("x32" [T,H] final hidden states, "qkv" [T,3H], "ctx" [T,H],
- * "ffn" [T,F], "pre32" [T,H]; with num_layers = 1 these are the layer-0 probes). */
+ * "ffn" [T,F], "pre32" [T,H]; with num_layers = 1 these are the layer-0 probes).
+ * bf16 batches of >= 1024 tokens run with LayerNorm folded into the GEMM epilogues and
+ * never materialise "x32" / "pre32" as such: "x32" is then an error (CSS_ENC_FUSE_LN=0
+ * keeps the separate LayerNorm kernels), "pre32" / "ctx" / "ffn" hold that path's buffers. */
 int css_encoder_debug_read(css_encoder* enc, const char* what, float* out_host, int64_t numel);
 
 /* Host-only helper (no device needed): bucket of a relative position

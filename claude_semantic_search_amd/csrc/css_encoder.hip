@@ -283,6 +283,8 @@ int ensure_acts(css_encoder* e, int T, int B) {
                 CSS_HIP_TRY(hipMalloc((void**)&e->stats[i], cap * 16));
                 CSS_HIP_TRY(hipMemset(e->stats[i], 0, cap * 16));  // slack rows: finite values
             }
+            // the memsets run on the null stream, forwards on non-blocking streams: order them here, once per growth
+            CSS_HIP_TRY(hipDeviceSynchronize());
         }
         e->cap_tokens = (int)cap;
     }

@@ -1763,6 +1763,8 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
     e = hipEventCreateWithFlags(&ix->ingest_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, sizeof(int));
     if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, sizeof(int));
+    // (null-stream memset vs the non-blocking streams every later launch uses: order it here, once)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
         (void)hipStreamDestroy(ix->stream);

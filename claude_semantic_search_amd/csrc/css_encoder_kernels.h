@@ -783,6 +783,8 @@ __global__ __launch_bounds__(512) void k_gemm16(const bf16_t* __restrict__ A, co
 // the order the waves arrive in and a forward pass stays bit-reproducible.  mu = sum / H, rs = rsqrt(sum^2 / H -
 // mu^2 + eps).  The EPI_AFF_* GEMM of a layer zeroes the statistics the following EPI_RES GEMM accumulates into.
 // Per tile the side data (bias or d row, c row, 256 row-statistic pairs) is DMA'd into LDS one tile ahead.
+// (range: sum^2 * 2^20 fits 63 bits up to a row sum of squares of 8.8e12, i.e. |pre| ~ 1e5 on all 768 columns; MPNet's
+// pre-LayerNorm activations are below 1e3.  Beyond it the conversion saturates and the row's statistics are wrong.)
 constexpr float kStatScale1 = 16777216.f, kStatScale2 = 1048576.f;
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void row_stats_decode(v4u32 raw, float inv_h, float eps, float& rs, float& mrs) {

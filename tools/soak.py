@@ -20,6 +20,17 @@ refm = ix.search(q[:40], 10, normalize=True, allow=allow)
 ids = [list(range(4, 4 + n)) for n in (5, 60, 384, 17)]
 ids = [[0] + s[:382] + [2] for s in ids]
 eref = enc.encode_ids(ids)
+# a batch of > 1024 tokens: the LayerNorm-folded GEMM path (integer-atomic row statistics: bit-reproducible)
+big = [[0] + [4 + (7 * i + j) % 30000 for j in range(n)] + [2] for i, n in enumerate((382, 200, 1, 333, 77, 250, 129, 64))]
+bref = enc.encode_ids(big)
+# a small clustered index whose queries overflow their candidate buffers: the device-side exact fix-up
+cent = synth.rows(40, 768, 11)
+cx = IndexFlatIP(768)
+cx.add(np.repeat(cent, 6000, axis=0) + 0.01 * synth.rows(240_000, 768, 12), normalize=True)
+cx.set_search_mode("coarse")
+cq = cent[:24] + 0.005 * synth.rows(24, 768, 13)
+cref = cx.search(cq, 10, normalize=True)
+assert cx.last_flagged() > 0
 free0 = torch.cuda.mem_get_info()[0]
 t0 = time.time(); it = 0
 while time.time() - t0 < secs:
@@ -30,6 +41,9 @@ while time.time() - t0 < secs:
     assert (I == refm[1]).all()
     e = enc.encode_ids(ids)
     assert np.array_equal(e, eref), f"encode changed at iteration {it}"
+    assert np.array_equal(enc.encode_ids(big), bref), f"folded-path encode changed at iteration {it}"
+    D, I = cx.search(cq, 10, normalize=True)
+    assert (I == cref[1]).all() and np.array_equal(D, cref[0]), f"fix-up search changed at iteration {it}"
     it += 1
     if it % 50 == 0:
         print(f"iteration {it}, {time.time() - t0:.0f}s, free HBM delta {(free0 - torch.cuda.mem_get_info()[0]) / 1e6:.1f} MB", flush=True)

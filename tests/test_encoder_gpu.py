@@ -78,6 +78,22 @@ def test_bf16_folded_layernorm_path_matches_oracle_and_is_bit_reproducible():
     enc.close()
 
 
+def test_bf16_folded_path_many_short_sequences():
+    """The folded path at the other extreme of its shape range: 700 sequences of 1..4 tokens (1024+ token rows, far
+    more sequences than row tiles; pooling partials for 700 sequences; attention blocks of a handful of keys)."""
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(1, 5, size=700).tolist()
+    assert sum(lengths) >= 1024
+    cfg, batch, ref = _oracle(2, lengths, 7, 17)
+    enc = MpnetEncoder(synthetic_seed=7, compute="bf16", cfg_overrides={"num_layers": 2})
+    out = enc.encode_ids(batch)
+    cos = (out * ref).sum(1)
+    assert cos.min() > 1 - 1e-3, cos.min()
+    assert np.abs(out - ref).max() < 2e-2
+    assert np.array_equal(out, enc.encode_ids(batch))
+    enc.close()
+
+
 def test_full_12_layer_bf16_and_fp32_vs_oracle():
     cfg, batch, ref = _oracle(12, [8, 40, 100, 384, 17, 250], 3, 4)
     for mode, tol in (("fp32", 3e-4), ("bf16", None)):

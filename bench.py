@@ -279,6 +279,11 @@ def bench_encoder(args, dev, log):
                          "total_tokens": Tm, "achieved_TFLOPs": fl2 / dt2 / 1e12,
                          "frac_of_bf16_peak": fl2 / dt2 / 1e12 / BF16_MFMA_PEAK_TF}
     log(f"encoder length mix: mean {lens.mean():.0f} tokens -> {B / dt2:.0f} chunks/s, {fl2 / dt2 / 1e12:.0f} TFLOP/s")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # N > 1 (one rank per GPU): the host-thread-heavy extras below (tokenizer on all cores, per-file encode loops)
+        # are single-GPU figures; N ranks running them at once would only oversubscribe the host
+        enc.close()
+        return res
 
     # ---- text path: strings -> C++ WordPiece tokenizer (host threads) -> encoder, tokenisation of the next
     # super-batch overlapped with the GPU (MpnetEncoder.encode); synthetic vocabulary and texts (no real

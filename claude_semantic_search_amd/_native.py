@@ -105,6 +105,7 @@ PROTOTYPES = {
     "css_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "css_encoder_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "css_encoder_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "css_encoder_set_attention_range": (c_int, [c_void_p, c_float]),
     "css_mpnet_rel_bucket": (c_int, [c_int, c_int, c_int]),
     "css_tokenizer_create": (c_int, [c_char_p, c_int, POINTER(c_void_p)]),
     "css_tokenizer_free": (c_int, [c_void_p]),
@@ -137,7 +138,12 @@ def lib() -> ctypes.CDLL:
         pass
     handle = ctypes.CDLL(str(LIB_PATH), mode=os.RTLD_NOW | os.RTLD_LOCAL if hasattr(os, "RTLD_NOW") else 0)
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(handle, name)
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            if os.environ.get("CSS_HIP_LIB"):  # an A/B build of an older tree (tools/build_variant.sh): newer entry points absent
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = handle

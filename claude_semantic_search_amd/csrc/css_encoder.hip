@@ -53,6 +53,8 @@ struct EncEnv {
     bool mfma16 = true;      // CSS_GEMM_MFMA=32: 32x32x16 MFMA kernel (k_gemm) instead of k_gemm16
     bool loop8 = true;       // CSS_GEMM_LOOP=old: the round-1 main loop (k_gemm16) instead of k_gemm8p
     bool fuse_ln = true;     // CSS_ENC_FUSE_LN=0: separate LayerNorm kernels also for large batches
+    float att_range = -1.f;  // CSS_ATT_RANGE: default of css_encoder_set_attention_range (0 = always the safe softmax pass)
+    int cg_qkv = 0, cg_ffn1 = 0, cg_o = 0, cg_ffn2 = 0;   // CSS_GEMM_CG="qkv,ffn1,o,ffn2": column-group tile walk of k_gemm8p (0 = N-fastest)
     EncEnv() {
         if (const char* t = getenv("CSS_GEMM_TILE")) big_tiles = atoi(t) != 128;
         if (const char* t = getenv("CSS_GEMM_DBG")) dbg = atoi(t);
@@ -60,6 +62,8 @@ struct EncEnv {
         if (const char* t = getenv("CSS_GEMM_MFMA")) mfma16 = atoi(t) != 32;
         if (const char* t = getenv("CSS_GEMM_LOOP")) loop8 = std::string(t) != "old";
         if (const char* t = getenv("CSS_ENC_FUSE_LN")) fuse_ln = atoi(t) != 0;
+        if (const char* t = getenv("CSS_ATT_RANGE")) att_range = (float)atof(t);
+        if (const char* t = getenv("CSS_GEMM_CG")) sscanf(t, "%d,%d,%d,%d", &cg_qkv, &cg_ffn1, &cg_o, &cg_ffn2);
     }
 };
 const EncEnv& enc_env() {
@@ -123,6 +127,7 @@ struct css_encoder {
     void *x16 = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;  // operand-typed
     long long* stats[2] = {nullptr, nullptr};        // [T][2] fixed-point row sums of the two pre tensors (folded-LN path)
     bool x32_valid = true;                           // false after a folded-LN forward (x32 is not materialised there)
+    float att_range = 1.2676506e30f;                 // 2^100: row-sum range of the reference-free softmax pass (attn_pass); 0 = always the SAFE pass
     int32_t *ids_dev = nullptr, *cu_dev = nullptr;
     float* out_dev = nullptr;
     // hipGraph cache for the launch-bound tiny-batch path (generate_single_embedding): key =
@@ -329,6 +334,7 @@ template <int EPI>
 int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   float qscale, const G8Side& side, int num_cus, hipStream_t st, const char* prof) {
     CSS_REQUIRE(N % 256 == 0 && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32), "gemm8p: bad shape %d x %d x %d", M, N, K);
+    CSS_REQUIRE(EPI != EPI_RES || K >= 256, "gemm8p: EPI_RES needs K >= 256 (statistics are flushed in a tile's third K step)");
     auto kern = k_gemm8p<EPI>;
     constexpr size_t lds = 2 * 4 * G8_HT;
     int dev_ = 0;
@@ -443,7 +449,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
                 const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
                 const int nqb = (max_len + 127) / 128;
                 hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st,
-                                   (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);
+                                   (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads, e->att_range);
             } else {
                 hipLaunchKernelGGL(k_attention_f32, dim3(B, max_len, c.heads), dim3(64), 0, st, (const float*)e->qkv, cu,
                                    e->bias_tab, maxL, H, (float*)e->ctx);
@@ -496,6 +502,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         // x = LN(pre[0]) -> qkv; zeroes stats[1]
         side.stats_in = e->stats[0];
         side.stats_out = e->stats[1];
+        side.cgroup = enc_env().cg_qkv;
         if ((rc = launch_gemm8p<EPI_AFF_QKV>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
                                              side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
@@ -504,22 +511,25 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
             const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
             const int nqb = (max_len + 127) / 128;
             hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st, (const bf16_t*)e->qkv, cu,
-                               e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads);
+                               e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads, e->att_range);
             CSS_LAUNCH_CHECK();
         }
         // pre[1] = ctx Wo^T + (bo + beta) + gamma (pre[0] - mu) rs; stats[1] += row sums
         side.pprev = pre[0];
         side.cvec = g_in;
+        side.cgroup = enc_env().cg_o;
         if ((rc = launch_gemm8p<EPI_RES>(e->ctx, L.wo_h, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
         side.stats_in = e->stats[1];
         side.stats_out = e->stats[0];
+        side.cgroup = enc_env().cg_ffn1;
         if ((rc = launch_gemm8p<EPI_AFF_GELU>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         // pre[0] = ffn W2^T + (b2 + beta1) + gamma1 (pre[1] - mu) rs; stats[0] += row sums
         side.pprev = pre[1];
         side.cvec = L.ln1g;
+        side.cgroup = enc_env().cg_ffn2;
         if ((rc = launch_gemm8p<EPI_RES>(e->ffn, L.w2_h, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         g_in = L.ln2g;
@@ -579,6 +589,7 @@ int css_encoder_create(const css_encoder_cfg* cfg, int device, css_encoder** out
     css_encoder* e = new css_encoder();
     e->cfg = *cfg;
     e->device = device;
+    if (enc_env().att_range >= 0.f) e->att_range = enc_env().att_range;
     {
         hipDeviceProp_t p;
         if (hipGetDeviceProperties(&p, device) == hipSuccess) e->num_cus = p.multiProcessorCount;
@@ -703,6 +714,18 @@ int css_encoder_export_weight(const css_encoder* ce, const char* name, float* ou
                 (long long)it->second.numel, (long long)numel);
     DeviceGuard g(e->device);
     CSS_HIP_TRY(hipMemcpy(out_host, it->second.p, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return CSS_OK;
+}
+
+int css_encoder_set_attention_range(css_encoder* e, float range) {
+    CSS_REQUIRE(e, "css_encoder_set_attention_range: NULL encoder");
+    CSS_REQUIRE(range == 0.f || (range >= 1.f && range <= 1.2676506e30f), "css_encoder_set_attention_range: range must be 0 or in [1, 2^100]");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->att_range = range;
+    // captured tiny-batch graphs hold the old kernel argument
+    for (auto& kv : e->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    e->graphs.clear();
     return CSS_OK;
 }
 

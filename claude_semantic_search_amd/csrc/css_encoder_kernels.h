@@ -796,6 +796,12 @@ __device__ __forceinline__ void row_stats_decode(v4u32 raw, float inv_h, float e
     rs = rsqrtf(fmaxf(var, 0.f) + eps);
     mrs = mu * rs;
 }
+__device__ __forceinline__ int g8_tile(int idx, int xfirst, int ntn, int cg, int cg_per) {
+    if (cg == 0) return xfirst + idx;
+    const int g = idx / cg_per, rem = idx - g * cg_per;
+    const int r = rem / cg, c = g * cg + (rem - r * cg);
+    return xfirst + r * ntn + c;
+}
 struct G8Side {
     const long long* stats_in;   // [T][2] raw row sums of the GEMM's input pre (AFF) / of the residual's pre (RES)
     const float* cvec;       // [N]    RES: gamma of the LayerNorm that makes the residual (its beta is in `bias`)
@@ -803,6 +809,7 @@ struct G8Side {
     long long* stats_out;    // [T][2] RES: row sums of the pre written by this GEMM; AFF: zeroed for the next EPI_RES GEMM
     float inv_h;             // 1 / hidden
     float eps;
+    int cgroup;              // > 0: tile walk in column groups of `cgroup` tile columns (see G8_TILE)
 };
 #if defined(G8_EXP) && (G8_EXP & 16)
 #define G8_SIDE_WAVES 2
@@ -844,6 +851,15 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     const int KT = K / 64;                 // even (host check)
     const int total = my_ntiles * KT;      // K steps of this block
     if (total == 0) return;
+    // Tile walk inside the XCD's range.  Default: N-fastest, so the 32 blocks of an XCD work side by side on a few
+    // row panels x ALL tile columns -- the whole weight matrix passes through the XCD's 4 MiB L2 once per round
+    // (FFN1: 4.7 MB of weights x 18 rounds x 8 XCDs = 680 MB of L2 misses per launch for 156 MB of operands).  With
+    // side.cgroup = g (and a rectangular range: whole row panels) the XCD finishes column group 0 (g tile columns:
+    // g x 393 KB of weights, resident) for all its row panels before group 1: activations are read ntn / g times,
+    // weights once per XCD.
+    const int cg = (side.cgroup > 0 && ntn % side.cgroup == 0 && xfirst % ntn == 0 && xcount % ntn == 0) ? side.cgroup : 0;
+    const int cg_per = cg ? (xcount / ntn) * cg : 1;   // tiles per column group
+#define G8_TILE(IDX_) g8_tile((IDX_), xfirst, ntn, cg, cg_per)
 
     // ---- DMA bookkeeping: one 32-bit source offset per half-tile kind (its first 1-KiB piece; the second piece is 8
     // rows further and its swizzled chunk differs by XOR 4), advanced independently.  Rows beyond M read the slack
@@ -857,7 +873,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     const unsigned row8 = 8u * (unsigned)K * 2u;
 #define G8_SET_SRC(KIND_)                                                                                     \
     {                                                                                                         \
-        const int tile_ = xfirst + jx + it_tile[KIND_] * per_x;                                               \
+        const int tile_ = G8_TILE(jx + it_tile[KIND_] * per_x);                                               \
         const int r0_ = (tile_ / ntn) * BM, c0_ = (tile_ % ntn) * BN;                                         \
         int srow_, grow_;                                                                                     \
         if ((KIND_) == G8_A0 || (KIND_) == G8_A1) {                                                           \
@@ -894,7 +910,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 // tile's 256 row-statistic pairs)
 #define G8_BIAS(TI_)                                                                                          \
     if (wave < ((AFF || RES) ? G8_SIDE_WAVES : 1) && !((AFF) && wave == 1)) {                                 \
-        const int tile_b = xfirst + jx + (TI_) * per_x;                                                       \
+        const int tile_b = G8_TILE(jx + (TI_) * per_x);                                                       \
         const float* sp_ = wave == 0 ? bias + (tile_b % ntn) * BN                                             \
                          : (wave == 1 ? side.cvec + (tile_b % ntn) * BN                                       \
                                       : reinterpret_cast<const float*>(side.stats_in + (size_t)(tile_b / ntn) * BM * 2) + (wave - 2) * 256);  \
@@ -981,6 +997,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     __builtin_amdgcn_s_barrier();      \
     __builtin_amdgcn_sched_barrier(0);
     int ct_tile = 0, kt = 0;
+    int flush_row0 = 0;   // EPI_RES: first row of this wave row's block in the tile whose statistics await G8_STATS_FLUSH
 // row statistics of the current tile (in LDS since the previous tile's first K step): wave row 0 turns the 256 raw
 // (sum, sum^2) pairs into (rs, mu rs) in place, once per tile, during the tile's second K step; the epilogues of all
 // waves read them many barriers later.  (Inline-asm LDS access: see the header comment.)
@@ -999,6 +1016,29 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         row_stats_decode(raw_, side.inv_h, side.eps, rs_, mrs_);                                              \
         const v2f_ o_ = {rs_, mrs_};                                                                          \
         asm volatile("ds_write_b64 %0, %1" : : "v"(so_), "v"(o_) : "memory");                                 \
+    }
+// EPI_RES: statistics of the PREVIOUS tile (partials of the wave row's four waves in their transpose scratch since the
+// end of that tile's epilogue; >= 20 block barriers ago for every wave) -> one fixed-order sum per row, then fixed-point
+// integer atomics (the order in which tile columns arrive does not matter: bit-reproducible).  Wave wc handles slots
+// 16 wc .. 16 wc + 15 (slot s = rows s and 64 + s of the 128-row block).
+#define G8_STATS_FLUSH()                                                                                      \
+    if constexpr (RES) {                                                                                      \
+        if (lane < 16) {                                                                                      \
+            const int sl_ = 16 * wc + lane;                                                                   \
+            const unsigned fo_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wr * 4] + sl_ * 16); \
+            v4f q0_, q1_;                                                                                     \
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"        \
+                         : "=&v"(q0_), "=&v"(q1_) : "v"(fo_), "n"(16 * EPI_ROW) : "memory");                  \
+            v4f t_ = q0_ + q1_;                                                                               \
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" \
+                         : "=&v"(q0_), "=&v"(q1_) : "v"(fo_), "n"(32 * EPI_ROW), "n"(48 * EPI_ROW) : "memory"); \
+            t_ += q0_ + q1_;                                                                                  \
+            unsigned long long* so_ = reinterpret_cast<unsigned long long*>(side.stats_out) + (size_t)(flush_row0 + sl_) * 2; \
+            atomicAdd(so_, (unsigned long long)__float2ll_rn(t_[0] * kStatScale1));                           \
+            atomicAdd(so_ + 1, (unsigned long long)__float2ll_rn(t_[1] * kStatScale2));                       \
+            atomicAdd(so_ + 128, (unsigned long long)__float2ll_rn(t_[2] * kStatScale1));                     \
+            atomicAdd(so_ + 129, (unsigned long long)__float2ll_rn(t_[3] * kStatScale2));                     \
+        }                                                                                                     \
     }
 #define G8_KSTEP(D_)                                                                                          \
     {                                                                                                         \
@@ -1030,6 +1070,8 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         G8_SYNC_A()                                                                                           \
         G8_MFMA(1, 0, b0)                                                                                     \
         G8_SYNC_B()                                                                                           \
+        /* (between K steps every fragment register is dead: the one place with room for the flush) */        \
+        if (RES && kt == 2 && ct_tile > 0) G8_STATS_FLUSH()                                                   \
         ++g;                                                                                                  \
         ++kt;                                                                                                 \
     }
@@ -1039,7 +1081,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         G8_KSTEP(1)
         if (kt == KT) {
             // ---- epilogue of output tile ct_tile (no block barrier inside: the stagger carries over)
-            const int tile = xfirst + jx + ct_tile * per_x;
+            const int tile = G8_TILE(jx + ct_tile * per_x);
             const int col0 = (tile % ntn) * BN + wc * 64;
             const unsigned wbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + lq * EPI_ROW + 8 * lg);
             const unsigned rbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + (lane >> 3) * EPI_ROW + (lane & 7) * 16);
@@ -1184,17 +1226,15 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                 __builtin_nontemporal_store(o1, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m + 8) * N));
             }
             if constexpr (RES) {
-                // every lane reports two rows (fixed-point integer adds: the order of arrival does not matter)
-                unsigned long long* so = reinterpret_cast<unsigned long long*>(side.stats_out) +
-                                         (size_t)((tile / ntn) * BM + wr * 128 + 16 * lg + lq) * 2;
-#if !defined(G8_EXP) || !(G8_EXP & 1)
-                atomicAdd(so, (unsigned long long)__float2ll_rn(keep[0] * kStatScale1));
-                atomicAdd(so + 1, (unsigned long long)__float2ll_rn(keep[1] * kStatScale2));
-                atomicAdd(so + 128, (unsigned long long)__float2ll_rn(keep[2] * kStatScale1));
-                atomicAdd(so + 129, (unsigned long long)__float2ll_rn(keep[3] * kStatScale2));
-#else
-                if (keep[0] + keep[1] + keep[2] + keep[3] == 12345.678f) so[0] = 1;
-#endif
+                // Row sums over this wave's 64 columns: lane (lq, lg) holds rows 16 lg + lq and 64 + 16 lg + lq of the wave
+                // row's 128-row block, i.e. slot `lane` of a [64][4]-float array in the wave's transpose scratch.  The four
+                // waves of a wave row are combined from there during the NEXT tile's third K step (G8_STATS_FLUSH): one
+                // set of integer atomics per row and tile instead of four (round 2: every lane of every wave issued its
+                // own 4 atomics, 0.26 ms per forward).
+                const unsigned ko_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(sepi[wave] + lane * 16);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)"
+                             : : "v"(ko_), "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]) : "memory");
+                flush_row0 = __builtin_amdgcn_readfirstlane((tile / ntn) * BM + wr * 128);
             }
             // bias row of the NEXT tile (in LDS since P2 of this tile's first K step) -> accumulator start values
             G8_ACC_FROM_BIAS((ct_tile + 1) & 1)
@@ -1203,6 +1243,11 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
+    if constexpr (RES) {   // statistics of the block's last tile
+        __builtin_amdgcn_s_barrier();
+        G8_STATS_FLUSH()
+    }
+#undef G8_STATS_FLUSH
 #undef G8_KSTEP
 #undef G8_SYNC_A
 #undef G8_SYNC_B
@@ -1211,6 +1256,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 #undef G8_READ_B
 #undef G8_ACC_FROM_BIAS
 #undef G8_BIAS
+#undef G8_TILE
 #undef G8_ISSUE
 #undef G8_SET_SRC
 }
@@ -1311,14 +1357,194 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const TIn* __restrict__ A, 
 // (Measured alternatives: __launch_bounds__(256, 4) -- 120 instead of 150 registers, four blocks per CU -- took this
 // latency-bound kernel from 3.1 to 2.46 ms per batch; a variant with one block per (sequence, head) and three
 // 32-query groups per wave, staging K/V once, needs 239 registers and ran 4.1 ms: occupancy beats reuse here.)
+// max over the two 32-lane halves (lane l <-> lane l ^ 32) on the VALU (v_permlane32_swap_b32: no LDS round trip).
+// (Plain fmaxf on purpose: an inline-asm v_max3 directly behind the MFMAs would read their results without the wait
+// states hipcc's hazard recognizer inserts for instructions it knows.)
+__device__ __forceinline__ float halfmax(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// V tile in LDS: row-major 128-B rows whose 64-B halves are exchanged on rows with bit 1 set.  A ds_read_b64_tr_b16
+// covers 4 consecutive key rows x 64 B per 32-lane group and banks are (a / 4) mod 64, i.e. rows r and r + 2 of a
+// linear image collide (2-way conflict on every transposed read: SQ_LDS_BANK_CONFLICT 0.16 in round 2); with the
+// exchange the four rows of a group land on four different 64-B quarters of the 256-B bank row.
+__device__ __forceinline__ int vswz_byte(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// One pass over the keys of the block's (sequence, head) for this wave's 32 queries.  SAFE = false: the
+// exponentials are taken WITHOUT a reference, p = exp2(score) (scores in the log2 domain), so a tile costs no
+// running maximum, no vote, no branch and no subtraction: the bias values read from LDS land directly in the
+// accumulators the QK^T MFMAs start from.  That is exact as long as the row sums stay inside the fp32 range; the
+// caller checks sum in (2^-100, 2^100) for every query of the block and otherwise repeats the block with SAFE =
+// true, the online softmax with a running maximum (reference 0 until a score exceeds it).  Attention logits of
+// a trained encoder are a few tens at most (|score| < 69 = 100 ln 2 is the fast path's range), so the repeat is a
+// guard, not a path that runs; tests force it with CSS_ATT_RANGE=0.
+template <int HD, bool SAFE>
+__device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char* Ks, char* Vs, const float* bt, int tok0, int L,
+                                           int head, int hidden, int maxL, int qic, const v4f (&qf)[4], f32x16 (&oacc)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ld = 3 * hidden;  // row stride of qkv in elements
+    const int nkt = (L + 63) / 64;
+    const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
+    v4f rk[2], rv[2];
+#define AT_GLOAD(KT_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+        int key = (KT_) * 64 + srow + 32 * i;                                                       \
+        key = key < L ? key : L - 1;                                                                \
+        const bf16_t* base = qkv + (size_t)(tok0 + key) * ld + head * HD + schunk * 8;              \
+        rk[i] = *reinterpret_cast<const v4f*>(base + hidden);                                       \
+        rv[i] = *reinterpret_cast<const v4f*>(base + 2 * hidden);                                   \
+    }
+#define AT_SSTORE(BUF)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+        *reinterpret_cast<v4f*>(Ks + (BUF) * 8192 + swz_byte(srow + 32 * i, schunk)) = rk[i];       \
+        *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + vswz_byte(srow + 32 * i, schunk)) = rv[i];      \
+    }
+    AT_GLOAD(0)
+    AT_SSTORE(0)
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+    float mrun = 0.f, lrun = 0.f;   // SAFE: mrun = reference of the exponentials = running maximum after the first tile
+
+    // transposed V reads: lane 4q+p of a 16-lane group addresses key row +q, columns d0 + 4p .. 4p+3
+    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int vflip = (q4 >> 1) & 1;   // = bit 1 of the key row (the other row terms are multiples of 4)
+    const int vlane = (4 * fh + q4) * 128 + 32 * g16 + 8 * p4;   // + (16 st [+ 8]) * 128 + ((mt ^ vflip) * 64)
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+#if !defined(ATT_DBG) || !(ATT_DBG & (1 | 128))
+        if (kt + 1 < nkt) {
+            AT_GLOAD(kt + 1)
+        }
+#endif
+        const char* Kb = Ks + cur * 8192;
+        const char* Vb = Vs + cur * 8192;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = kt * 64 + sub * 32;
+            if (key0 >= L) break;  // block-uniform
+            // S^T[key][query] = K[key][:] . Q[query][:] + bias (- mrun): the accumulator STARTS at the bias from the LDS
+            // table (SAFE: minus this query's running maximum), so the scores leave the MFMAs ready for the exponential.
+            // Keys beyond the sequence start at -inf (last, partial tile only).  Scores are in the log2 domain: q was
+            // pre-scaled by log2(e)/8 and bias_tab by log2(e), so the softmax uses v_exp_f32 (exp2) directly.
+            f32x16 s;
+            {
+                const float* bl = bt + (key0 + 4 * fh - qic + (maxL - 1));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {   // (the table has 64 entries of padding)
+#if defined(ATT_DBG) && (ATT_DBG & 4)
+                    s[r] = 0.f;
+#else
+                    if constexpr (SAFE) s[r] = bl[(r & 3) + 8 * (r >> 2)] - mrun;
+                    else s[r] = bl[(r & 3) + 8 * (r >> 2)];
+#endif
+                }
+                if (key0 + 32 > L) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + 4 * fh + (r & 3) + 8 * (r >> 2) >= L) s[r] = -INFINITY;
+                }
+            }
+#if !defined(ATT_DBG) || !(ATT_DBG & 32)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[ks]), s, 0, 0, 0);
+            }
+#endif
+            if constexpr (SAFE) {
+                float mloc = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+                mloc = halfmax(mloc);   // finite: key0 < L means at least one valid key
+                // the reference moves when a score exceeds it (first tiles mostly) and always on the first tile, whose
+                // reference was the arbitrary 0: shift the scores, rescale the running sums
+                // (no tile summed yet: afterwards the query's sum is >= 1, the maximum's own term.  The test is on the sum of
+                // BOTH lane halves: a half whose own terms all underflowed would otherwise take the first-tile branch a
+                // second time, with a shift its partner does not make.)
+                const bool first = lrun + __shfl_xor(lrun, 32) == 0.f;
+                if (!__all(mloc <= 0.f && !first)) {
+                    const float d = first ? mloc : fmaxf(mloc, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] -= d;
+                    mrun += d;
+                    lrun *= alpha;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+                }
+            }
+            float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+#if defined(ATT_DBG) && (ATT_DBG & 2)
+                const float p0 = s[r], p1 = s[r + 1];
+#elif defined(ATT_DBG) && (ATT_DBG & 64)
+                const float p0 = s[r] * s[r], p1 = s[r + 1] * s[r + 1];
+#else
+                const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+#endif
+                s[r] = p0;
+                s[r + 1] = p1;
+                lsum0 += p0;
+                lsum1 += p1;
+            }
+            lrun += lsum0 + lsum1;
+            // O^T[d][query] += V^T[d][key] . P^T[key][query]
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                v8bf pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * st + j];
+#if defined(ATT_DBG) && (ATT_DBG & 8)
+                oacc[st][0] += (float)pf[0] + (float)pf[7];
+#else
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    // lane (d = 32*mt + fr, half fh): keys {16st+4fh+0..3} and {16st+8+4fh+0..3}
+                    const char* vp = Vb + vlane + (sub * 32 + 16 * st) * 128 + ((mt ^ vflip) << 6);
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(vp));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(vp + 8 * 128));
+                    // whole-vector shuffle + bitcast: per-element short -> __bf16 bitcasts of the
+                    // tr-read result were miscompiled by hipcc 7.2 into a splat of element 0
+                    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v8bf vf = __builtin_bit_cast(v8bf, both);
+                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[mt], 0, 0, 0);
+                }
+#endif
+            }
+        }
+#if !defined(ATT_DBG) || !(ATT_DBG & (16 | 128))
+        if (kt + 1 < nkt) {
+            AT_SSTORE(cur ^ 1)
+        }
+        __syncthreads();
+#endif
+#if !defined(ATT_DBG) || !(ATT_DBG & 128)
+        cur ^= 1;
+#endif
+    }
+#undef AT_GLOAD
+#undef AT_SSTORE
+    return lrun + __shfl_xor(lrun, 32);
+}
+
+// `range`: the fast pass is kept when every row sum lies in (1 / range, range); 0 forces the SAFE pass (tests).
 template <int HD>
 __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,
-                                                        bf16_t* __restrict__ ctx, int nqb, int heads) {
+                                                        bf16_t* __restrict__ ctx, int nqb, int heads, float range) {
     static_assert(HD == 64, "head_dim 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                 // [2][64 keys][128 B]  (swizzled)
-    char* Vs = smem + 2 * 8192;      // [2][64 keys][128 B]  (row-major, d contiguous)
+    char* Vs = smem + 2 * 8192;      // [2][64 keys][128 B]  (row-major, halves exchanged: vswz_byte)
     float* bt = reinterpret_cast<float*>(smem + 4 * 8192);  // [2*maxL-1] + 64 (padding read by the last, partial tile)
 
     // 1-D grid of B * nqb * heads blocks.  The nqb query blocks of one (sequence, head) read the same K / V rows:
@@ -1335,149 +1561,45 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     if (q0 >= L) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const int ld = 3 * hidden;  // row stride of qkv in elements
-
-    const float* bsrc = bias_tab + (size_t)head * (2 * maxL - 1);
-    for (int i = tid; i < 2 * maxL - 1 + 64; i += 256) bt[i] = i < 2 * maxL - 1 ? bsrc[i] : 0.f;
 
     // this lane's query (clamped for loads; invalid queries are not stored)
     const int qi = q0 + wave * 32 + fr;
     const int qic = qi < L ? qi : L - 1;
     // Q fragments as B operand: lane holds Q[query][16*ks + 8*fh + j]
-    v8bf qf[4];
+    v4f qf[4];
     {
-        const bf16_t* qp = qkv + (size_t)(tok0 + qic) * ld + head * HD;
+        const bf16_t* qp = qkv + (size_t)(tok0 + qic) * (3 * hidden) + head * HD;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8bf*>(qp + 16 * ks + 8 * fh);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v4f*>(qp + 16 * ks + 8 * fh);
     }
+    {
+        const float* bsrc = bias_tab + (size_t)head * (2 * maxL - 1);
+        for (int i = tid; i < 2 * maxL - 1 + 64; i += 256) bt[i] = i < 2 * maxL - 1 ? bsrc[i] : 0.f;
+    }
+    // The Q fragments are pinned HERE (a use the compiler has to wait for).  Without it hipcc's wait-count pass
+    // cannot prove, at the QK^T MFMAs inside the loop, that the four Q loads have returned (vmcnt counts in order
+    // and one path into the loop issues no tile loads), so it put vmcnt(3) .. vmcnt(0) in front of the four MFMAs of
+    // every tile's first 32 keys -- every tile waited for the NEXT tile's global loads issued a few instructions
+    // earlier, and the register prefetch hid nothing (round 2: 2.5 ms per batch).
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
 
     f32x16 oacc[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
-    float mrun = 0.f, lrun = 0.f;   // mrun: reference of the exponentials = running maximum after the first tile
-
-    const int nkt = (L + 63) / 64;
-    const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
-    v4f rk[2], rv[2];
-#define AT_GLOAD(KT_)                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
-        int key = (KT_) * 64 + srow + 32 * i;                                                       \
-        key = key < L ? key : L - 1;                                                                \
-        const bf16_t* base = qkv + (size_t)(tok0 + key) * ld + head * HD + schunk * 8;              \
-        rk[i] = *reinterpret_cast<const v4f*>(base + hidden);                                       \
-        rv[i] = *reinterpret_cast<const v4f*>(base + 2 * hidden);                                   \
+    float ltot = 0.f;
+    bool ok = false;
+    if (range > 0.f) {
+        ltot = attn_pass<HD, false>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
+        ok = ltot < range && ltot * range > 1.0f;   // (NaN compares false)
     }
-#define AT_SSTORE(BUF)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
-        *reinterpret_cast<v4f*>(Ks + (BUF) * 8192 + swz_byte(srow + 32 * i, schunk)) = rk[i];       \
-        *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + (srow + 32 * i) * 128 + schunk * 16) = rv[i];   \
-    }
-    AT_GLOAD(0)
-    AT_SSTORE(0)
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) {
-            AT_GLOAD(kt + 1)
-        }
-        const char* Kb = Ks + cur * 8192;
-        const char* Vb = Vs + cur * 8192;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = kt * 64 + sub * 32;
-            if (key0 >= L) break;  // block-uniform
-            // S^T[key][query] = K[key][:] . Q[query][:] + bias - mrun: the accumulator STARTS at bias - mrun (bias from
-            // the LDS table, mrun = this query's running maximum), so the scores come out of the MFMAs already
-            // relative to the reference the exponentials use -- no zeroing, no bias add, no per-score subtraction
-            // afterwards (this kernel is bound by VALU issue slots).  Keys beyond the sequence start at -inf (last,
-            // partial tile only).  Scores are in the log2 domain: q was pre-scaled by log2(e)/8 and bias_tab by
-            // log2(e), so the softmax uses v_exp_f32 (exp2) directly.
-            f32x16 s;
-            {
-                const float* bl = bt + (key0 + 4 * fh - qic + (maxL - 1));
-                if (key0 + 32 <= L) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] = bl[(r & 3) + 8 * (r >> 2)] - mrun;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {   // (unconditional reads: the table has 64 entries of padding)
-                        const int ko = (r & 3) + 8 * (r >> 2);
-                        const float bv = bl[ko] - mrun;
-                        s[r] = key0 + 4 * fh + ko < L ? bv : -INFINITY;
-                    }
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), qf[ks], s, 0, 0, 0);
-            }
-            float mloc = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));   // finite: key0 < L means at least one valid key
-            // the reference moves when a score exceeds it (first tiles mostly) and always on the first tile, whose
-            // reference was the arbitrary 0: shift the scores, rescale the running sums
-            const bool first = lrun == 0.f;   // (no tile summed yet: afterwards lrun >= 1, the maximum's own term)
-            if (!__all(mloc <= 0.f && !first)) {
-                const float d = first ? mloc : fmaxf(mloc, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] -= d;
-                mrun += d;
-                lrun *= alpha;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
-            }
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[r]);
-                s[r] = p;
-                lsum += p;
-            }
-            lrun += lsum;
-            // O^T[d][query] += V^T[d][key] . P^T[key][query]
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                v8bf pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * st + j];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    // lane (d = 32*mt + fr, half fh): keys {16st+4fh+0..3} and {16st+8+4fh+0..3}
-                    // tr read: lane 4q+p of a 16-lane group addresses row key0'+q, columns d0+4p..4p+3
-                    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-                    const int dcol = 32 * mt + 16 * g16 + 4 * p4;
-                    const int kr0 = sub * 32 + 16 * st + 4 * fh + q4;
-                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (v4s __attribute__((address_space(3)))*)(Vb + kr0 * 128 + dcol * 2));
-                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (v4s __attribute__((address_space(3)))*)(Vb + (kr0 + 8) * 128 + dcol * 2));
-                    // whole-vector shuffle + bitcast: per-element short -> __bf16 bitcasts of the
-                    // tr-read result were miscompiled by hipcc 7.2 into a splat of element 0
-                    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const v8bf vf = __builtin_bit_cast(v8bf, both);
-                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[mt], 0, 0, 0);
-                }
-            }
-        }
-        if (kt + 1 < nkt) {
-            AT_SSTORE(cur ^ 1)
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-#undef AT_GLOAD
-#undef AT_SSTORE
-    const float ltot = lrun + __shfl_xor(lrun, 32);
+    if (!__syncthreads_and(ok)) ltot = attn_pass<HD, true>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
     const float inv = 1.0f / ltot;
-    if (qi < L) {
-        bf16_t* op = ctx + (size_t)(tok0 + qi) * hidden + head * HD;
+    // Output rows leave through a per-wave LDS transpose (the K / V tiles are dead: the pass ends with a block
+    // barrier): a lane owns HALF a query row in 8-byte pieces, so direct stores scatter 8-B pieces over 64 rows per
+    // instruction (store-issue bound: a quarter of a block's life in round 2); after the transpose 8 lanes write one
+    // full 128-B line as 16-B stores.  Rows padded to 144 B (as k_gemm8p's epilogue).
+    {
+        constexpr int OROW = 144;
+        char* ow = smem + wave * (32 * OROW);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1487,8 +1609,18 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
                 h.y = f2bf(oacc[mt][4 * g + 1] * inv);
                 h.z = f2bf(oacc[mt][4 * g + 2] * inv);
                 h.w = f2bf(oacc[mt][4 * g + 3] * inv);
-                *reinterpret_cast<ushort4*>(op + 32 * mt + 8 * g + 4 * fh) = h;
+                *reinterpret_cast<ushort4*>(ow + fr * OROW + (32 * mt + 8 * g + 4 * fh) * 2) = h;
             }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's own LDS writes before its reads (no other wave touches the region)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 8 * t + (lane >> 3);
+            const v4f o = *reinterpret_cast<const v4f*>(ow + row * OROW + (lane & 7) * 16);
+            const int q = q0 + wave * 32 + row;
+            if (q < L) *reinterpret_cast<v4f*>(ctx + (size_t)(tok0 + q) * hidden + head * HD + (lane & 7) * 8) = o;
+        }
     }
 }
 

@@ -131,6 +131,11 @@ class MpnetEncoder:
         nat.check(nat.lib().css_encoder_export_weight(self._h, name.encode(), out.ctypes.data, out.size))
         return out
 
+    def set_attention_range(self, value: float) -> None:
+        """Verification knob of the bf16 attention kernel (``css_encoder_set_attention_range``): 0 forces the
+        running-maximum softmax pass, the default 2**100 keeps the reference-free pass while row sums fit fp32."""
+        nat.check(nat.lib().css_encoder_set_attention_range(self._h, ctypes.c_float(value)))
+
     def debug_read(self, what: str, shape) -> np.ndarray:
         out = np.empty(shape, dtype=np.float32)
         nat.check(nat.lib().css_encoder_debug_read(self._h, what.encode(), out.ctypes.data, out.size))

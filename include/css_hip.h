@@ -190,6 +190,12 @@ int css_encoder_forward(css_encoder* enc, const int32_t* input_ids_host, const i
 int css_encoder_forward_dev(css_encoder* enc, const int32_t* input_ids_dev, const int32_t* cu_seqlens_dev,
                             int B, int total_tokens, int max_len, int normalize, float* out_dev, void* stream);
 
+/* bf16 attention computes softmax rows as exp2(score) / sum WITHOUT a running maximum while every row sum of a
+ * block stays in (1 / range, range) and repeats the block with the running-maximum (online) softmax otherwise --
+ * same result, the guard only protects the fp32 range.  Default 2^100 (|logit| < 69); range = 0 always takes the
+ * running-maximum pass (verification; env default CSS_ATT_RANGE). */
+int css_encoder_set_attention_range(css_encoder* enc, float range);
+
 /* Test/diagnostic hook: copy an activation buffer of the LAST forward back to the
  * host as fp32 ("x32" [T,H] final hidden states, "qkv" [T,3H], "ctx" [T,H],
  * "ffn" [T,F], "pre32" [T,H]; with num_layers = 1 these are the layer-0 probes).

@@ -335,3 +335,41 @@ def test_single_query_graph_replay_is_bit_stable():
     assert np.allclose(both[0], first[0], atol=1e-6) and np.array_equal(both, enc.encode_ids([a, b]))
     big = enc.encode_ids([list(a) * 60])  # 360 tokens: grows the activation buffers, graphs are dropped
     assert np.array_equal(first, enc.encode_ids([a])) and big.shape == (1, 768)
+
+
+@pytest.mark.parametrize("qk_gain", [1.0, 10.0])
+def test_attention_reference_free_pass_and_its_guard(qk_gain):
+    """k_attention_bf16 forms softmax rows as exp2(score) / sum without a running maximum while every row sum of
+    a block stays inside (2^-100, 2^100), and repeats the block with the running-maximum pass otherwise.  Both
+    passes must give the same embeddings: (a) ordinary logits -- the default takes the fast pass, range = 0 forces
+    the guarded one; (b) q / k weights scaled until logits reach the hundreds, where exp2(score) overflows fp32 and
+    the DEFAULT setting has to fall back by itself (no inf / NaN, same result as the forced pass, close to the
+    fp32 oracle as far as bf16 logits of that size allow)."""
+    from oracle import mpnet_oracle as mo
+
+    cfg = mo.MpnetCfg(num_layers=2)
+    w = mo.synth_weights(cfg, 21)
+    if qk_gain != 1.0:
+        for li in range(cfg.num_layers):
+            for nm in ("q", "k"):
+                w[f"encoder.layer.{li}.attention.attn.{nm}.weight"] = w[f"encoder.layer.{li}.attention.attn.{nm}.weight"] * qk_gain
+    lengths = [384, 129, 64, 33, 300, 1, 383, 200]    # 1494 tokens: the folded path; + a small batch below
+    batch = mo.synth_batch(cfg, lengths, seed=4)
+    ref = mo.encode(w, cfg, batch)
+    enc = MpnetEncoder(synthetic_seed=21, compute="bf16", cfg_overrides={"num_layers": 2})
+    enc.load_state_dict({k: v.numpy() for k, v in w.items()})
+    for sub in (batch, batch[1:4]):
+        enc.set_attention_range(2.0 ** 100)
+        fast = enc.encode_ids(sub)
+        enc.set_attention_range(0.0)
+        safe = enc.encode_ids(sub)
+        assert np.isfinite(fast).all() and np.isfinite(safe).all()
+        assert np.abs(fast - safe).max() < 2e-3, np.abs(fast - safe).max()
+        r = ref if len(sub) == len(batch) else ref[1:4]
+        cos = (safe * r).sum(1)
+        assert cos.min() > (1 - 1e-3 if qk_gain == 1.0 else 0.95), cos
+    if qk_gain != 1.0:   # the logits really are outside the fast pass's range
+        qkv = enc.debug_read("qkv", (sum(lengths[1:4]), 3 * 768))
+        q0, k0 = qkv[:129, :64], qkv[:129, 768:768 + 64]      # sequence of 129 tokens, head 0 (q pre-scaled to log2 units)
+        assert np.abs(q0 @ k0.T).max() > 110
+    enc.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/enc_ab.sh "ENV1=.. ENV2=.." ...   -> one line per variant with per-kernel ms
 for v in "$@"; do
-  env $v timeout -k 10 300 python bench.py --only-encoder --no-cpu-baseline 2>/dev/null | python -c "
+  env $v timeout -k 10 300 python bench.py --only-encoder --enc-fixed-only --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
 try:
     e=json.loads(sys.stdin.read())['encode']

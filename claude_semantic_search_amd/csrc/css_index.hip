@@ -78,6 +78,12 @@ struct css_index {
     // export wait for this event before touching rows, norms or maxn2
     hipEvent_t ingest_ev = nullptr;
     bool ingest_pending = false;
+    // every search shares ONE set of workspaces (qpad, gthr, cthr, cand_*, cflags, fix_*, part_*): ws_mu serialises the
+    // host-side enqueue only, so the last search's stream is remembered and a search on ANOTHER stream first waits
+    // for this event (recorded at the end of each search) before it overwrites them
+    hipEvent_t ws_ev = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
     const int* last_nflag = nullptr;   // device counter of the last candidate-path search (css_index_last_flagged)
     std::shared_mutex mu;  // search: shared; add/reset/reserve: exclusive
     std::mutex ws_mu;      // workspaces + own stream are single-user
@@ -1440,9 +1446,16 @@ int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_
 // ranks per query, and k_coarse_select<FINAL> rescores the band in fp32 exactly as the bf16 cascade does.  A
 // query whose band does not close inside the kept ranks is flagged and re-run by the device-side fix-up.
 template <int METRIC>
-int launch_scan_split_rescore(css_index* ix, int nq, int k, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
+int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
                               hipStream_t st) {
+    // queries [q0, q0 + nq) of the padded query rows; nq <= 4096 and q0 a multiple of 256 (the caller chunks: the
+    // candidate buffers are 32 KiB per query, and only the last chunk has padding rows to clear)
     const int kp = k + kSplitExtra;
+    float* const qpad = ix->qpad + (size_t)q0 * ix->dpad;
+    float* const qnorm2 = ix->qnorm2 + q0;
+    int* const gthr = ix->gthr + q0;
+    D_dev += (size_t)q0 * k;
+    I_dev += (size_t)q0 * k;
     const bool big = nq > 128 && kp <= 14;  // 256x256 tiles (8 waves) for real batches
     const int BMs = big ? 256 : MF_BM, BNs = big ? 256 : MF_BN;
     const int nq_pad = (nq + BNs - 1) / BNs * BNs;  // <= nq + 255 (qpad / gthr have 256 rows of slack)
@@ -1463,12 +1476,12 @@ int launch_scan_split_rescore(css_index* ix, int nq, int k, float* D_dev, int64_
     int* nflag = ix->cflags + 2 * nq_pad;
     ix->last_nflag = nflag;
     if (nq_pad > nq)
-        CSS_HIP_TRY(hipMemsetAsync(ix->qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
-    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->gthr, nq_pad, host_f2key(-INFINITY));
+        CSS_HIP_TRY(hipMemsetAsync(qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
+    hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, gthr, nq_pad, host_f2key(-INFINITY));
     hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags, nflag,
                        nq, nq_pad, 0);
     const int64_t ne = (int64_t)nq_pad * ix->dpad;
-    hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ix->qpad, ix->qsplit,
+    hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qsplit,
                        (int64_t)nq_pad, ix->dpad);
     CSS_LAUNCH_CHECK();
     ProfScope all("knn_split_cascade", st);
@@ -1478,26 +1491,26 @@ int launch_scan_split_rescore(css_index* ix, int nq, int k, float* D_dev, int64_
             auto kern = k_scan_mfma_split<METRIC, 8, 8>;
             if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
             hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(512), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
+                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, gthr, ix->part_s, ix->part_i, ix->cur_mask);
         } else {
             auto kern = k_scan_mfma_split<METRIC, 4, 4>;
             if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
             hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qsplit, nq,
-                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
+                               ix->ntotal, ix->dpad, kp, nstrips, nqtiles, tps, gthr, ix->part_s, ix->part_i, ix->cur_mask);
         }
         CSS_LAUNCH_CHECK();
     }
     // the kp best split scores of every query -> its candidate buffer (scores stay in the scan's form: IP dot
     // products, L2 2 x.q - ||x||^2, the form k_coarse_select expects of coarse scores)
-    hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, ix->gthr,
-                       ix->qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
+    hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, gthr,
+                       qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
                        ix->cand_n);
     hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
-                       flags, nflag, flag_list, ix->qnorm2, ix->maxn2, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, k,
-                       ix->qpad, ix->xb, ix->dpad, ix->id_base, D_dev, I_dev, kp, ix->gthr, ix->fix_s, ix->fix_i,
+                       flags, nflag, flag_list, qnorm2, ix->maxn2, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, k,
+                       qpad, ix->xb, ix->dpad, ix->id_base, D_dev, I_dev, kp, gthr, ix->fix_s, ix->fix_i,
                        ix->fix_lock);
     CSS_LAUNCH_CHECK();
-    return launch_fixup(ix, ix->qpad, nq, k, ix->gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
+    return launch_fixup(ix, qpad, nq, k, gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
                         sg, st);
 }
 
@@ -1664,8 +1677,25 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
 }
 
 // q_dev: raw [nq, dim] device queries.  Caller holds ws_mu and a shared lock on mu.
+int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
+                       int64_t* I_dev, hipStream_t st);
 int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
                       int64_t* I_dev, hipStream_t st) {
+    // the previous search may still be running on another stream and owns the shared workspaces until its event
+    if (ix->ws_pending && ix->ws_stream != st) CSS_HIP_TRY(hipStreamWaitEvent(st, ix->ws_ev, 0));
+    const int rc = search_dev_enqueue(ix, q_dev, nq, k, normalize_q, D_dev, I_dev, st);
+    // (also after a failed enqueue: whatever was launched before the error still uses the workspaces)
+    if (hipEventRecord(ix->ws_ev, st) == hipSuccess) {
+        ix->ws_stream = st;
+        ix->ws_pending = true;
+    } else {
+        (void)hipDeviceSynchronize();
+        ix->ws_pending = false;
+    }
+    return rc;
+}
+int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
+                       int64_t* I_dev, hipStream_t st) {
     CSS_REQUIRE(k >= 1 && k <= CSS_MAX_K, "css_index_search: k=%d outside [1, %d]", k, CSS_MAX_K);
     CSS_REQUIRE(nq >= 0 && nq < (1 << 24), "css_index_search: nq=%lld out of range", (long long)nq);
     if (nq == 0) return CSS_OK;
@@ -1720,8 +1750,19 @@ int search_dev_locked(css_index* ix, const float* q_dev, int64_t nq, int k, int 
     }
     // no shadow rows: batches still take a candidate path, with split-operand coarse scores from the fp32 rows
     if (batch_ok && k + kSplitExtra <= kMfmaMaxK && (env.batch == 1 || (want_candidates && ix->xh == nullptr))) {
-        return ix->metric == CSS_METRIC_IP ? launch_scan_split_rescore<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, sg, st)
-                                           : launch_scan_split_rescore<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, sg, st);
+        for (int64_t q0 = 0; q0 < nq; q0 += 4096) {   // (chunked like the bf16 cascade: candidate buffers are per query)
+            const int nqc = (int)std::min<int64_t>(4096, nq - q0);
+            rc = ix->metric == CSS_METRIC_IP ? launch_scan_split_rescore<CSS_METRIC_IP>(ix, (int)q0, nqc, k, D_dev, I_dev, sg, st)
+                                             : launch_scan_split_rescore<CSS_METRIC_L2>(ix, (int)q0, nqc, k, D_dev, I_dev, sg, st);
+            if (rc != CSS_OK) return rc;
+        }
+        return CSS_OK;
+    }
+    // shadow-less batches whose k leaves no room for the split scan's extra ranks (k = 61 .. 64): the fp32-input MFMA
+    // scan, not 16-query VALU sweeps
+    if (batch_ok && want_candidates && ix->xh == nullptr) {
+        return ix->metric == CSS_METRIC_IP ? launch_scan_fp32mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
+                                           : launch_scan_fp32mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
     }
     // exact fp32 arithmetic inside the scan: fp32-input MFMA for batches, VALU sweeps for up to 16 queries
     if (batch_ok && (mode == CSS_SEARCH_EXACT_FP32 || env.batch == 2)) {
@@ -1760,6 +1801,12 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
         delete ix;
         return css::hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
     }
+    e = hipEventCreateWithFlags(&ix->ws_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ix->stream);
+        delete ix;
+        return css::hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+    }
     e = hipEventCreateWithFlags(&ix->ingest_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, sizeof(int));
     if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, sizeof(int));
@@ -1767,6 +1814,7 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
+        if (ix->ws_ev) (void)hipEventDestroy(ix->ws_ev);
         (void)hipStreamDestroy(ix->stream);
         delete ix;
         return css::hip_fail(e, "hipMalloc(maxn2)", __FILE__, __LINE__);
@@ -1786,6 +1834,7 @@ int css_index_free(css_index* ix) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
+    if (ix->ws_ev) (void)hipEventDestroy(ix->ws_ev);
     (void)hipStreamDestroy(ix->stream);
     delete ix;
     return CSS_OK;
@@ -1798,6 +1847,7 @@ int css_index_reset(css_index* ix) {
     if (!ix->xh) ix->shadow = -1;
     DeviceGuard g(ix->device);
     if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
+    if (ix->ws_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ws_ev, 0));   // a search enqueued on another stream still reads maxn2
     CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, sizeof(int), ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
@@ -1919,6 +1969,8 @@ int css_index_add_dev(css_index* ix, const float* x_dev, int64_t n, int normaliz
     DeviceGuard g(ix->device);
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc != CSS_OK) return rc;
+    // an earlier asynchronous add may have used another stream: chain it, so that the ONE event below covers it too
+    if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->ingest_ev, 0));
     for (int64_t r0 = 0; r0 < n; r0 += (1ll << 30)) {
         const int64_t m = std::min<int64_t>(1ll << 30, n - r0);
         if ((rc = ingest(ix, x_dev + (size_t)r0 * ix->dim, m, normalize, false, 0, 0, (hipStream_t)stream)) != CSS_OK)
@@ -1940,6 +1992,7 @@ int css_index_add_synthetic(css_index* ix, int64_t n, uint64_t seed, int64_t fir
     DeviceGuard g(ix->device);
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc != CSS_OK) return rc;
+    if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->ingest_ev, 0));
     for (int64_t r0 = 0; r0 < n; r0 += (1ll << 30)) {
         const int64_t m = std::min<int64_t>(1ll << 30, n - r0);
         if ((rc = ingest(ix, nullptr, m, normalize, true, seed, first_row + r0, (hipStream_t)stream)) != CSS_OK)

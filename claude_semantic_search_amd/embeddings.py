@@ -111,9 +111,10 @@ class EmbeddingBatcher:
         self._complete_ready()
 
     def _encode(self, n: int) -> None:
-        take, self._queue = self._queue[:n], self._queue[n:]
+        take = self._queue[:n]
         texts = [self._pending[s - self._base][1][i].text for s, i in take]
-        rows = self.gen._generate_embeddings_batch(texts)
+        rows = self.gen._generate_embeddings_batch(texts)   # (a failure leaves the chunks queued: flush() can be retried)
+        self._queue = self._queue[n:]
         self.batches.append(len(texts))
         for (s, i), row in zip(take, rows):
             key, chunks, out, done = self._pending[s - self._base]

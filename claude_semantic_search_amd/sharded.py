@@ -187,6 +187,9 @@ class ShardedFlatIndex:
         recv = recv_flat.view(self.world, record)
         if self._merge is None and q.is_cuda:
             return self._merge_packed_hip(recv, nq, k, record)
+        if self._merge is None:
+            raise RuntimeError("ShardedFlatIndex: the merge of the gathered top-k lists runs on the HIP device "
+                               "(css_merge_topk_packed_dev); queries on the CPU need merge=<callable> (test doubles only)")
         Ig = recv[:, :ib].view(torch.int64).view(self.world, nq, k)
         Dg = recv[:, ib:db].view(torch.float32).view(self.world, nq, k)
         return self._merge(Dg.contiguous(), Ig.contiguous(), k)

@@ -105,7 +105,23 @@ _SCHEMA = (
     "CREATE INDEX IF NOT EXISTS idx_chunks_has_code ON chunks(has_code)",
     "CREATE INDEX IF NOT EXISTS idx_chunks_has_tools ON chunks(has_tools)",
     "CREATE INDEX IF NOT EXISTS idx_chunks_faiss_id ON chunks(faiss_id)",
+    # build-owned: journal of the two-file operations (index file + SQLite) that must survive a crash between them
+    "CREATE TABLE IF NOT EXISTS storage_meta (key TEXT PRIMARY KEY, value TEXT)",
 )
+
+
+def _fsync_dir(path: Path) -> None:
+    """Make a rename inside ``path`` durable (POSIX: fsync of the directory; skipped where a directory cannot be opened)."""
+    try:
+        fd = os.open(str(path), os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        os.fsync(fd)
+    except OSError:
+        pass
+    finally:
+        os.close(fd)
 
 
 def _row_to_chunk(row) -> Chunk:
@@ -191,7 +207,27 @@ class HybridStorage:
     def _convert_to_cpu_index(self, gpu_index):
         return fi.index_gpu_to_cpu(gpu_index)
 
+    def _recover_interrupted_compaction(self) -> None:
+        """Finish or discard a compaction (``_rebuild_faiss_index``) that a crash interrupted.  Its order is:
+        (1) compacted rows -> ``<index>.compact``; (2) ONE SQLite transaction renumbers the ids and sets
+        ``storage_meta['pending_compact']``; (3) ``os.replace(<index>.compact, <index>)``; (4) the flag is cleared.
+        So: flag set -> SQLite already speaks the new numbering and the compacted file is either still beside the
+        index (finish step 3) or already in place; flag absent -> a leftover ``.compact`` was never committed."""
+        compact = Path(str(self.index_path) + ".compact")
+        row = self.db.execute("SELECT value FROM storage_meta WHERE key = 'pending_compact'").fetchone()
+        if row is not None:
+            if compact.exists():
+                os.replace(str(compact), str(self.index_path))
+                _fsync_dir(self.index_path.parent)
+                self.logger.warning("Completed an interrupted index compaction (compacted file moved into place)")
+            self.db.execute("DELETE FROM storage_meta WHERE key = 'pending_compact'")
+            self.db.commit()
+        elif compact.exists():
+            compact.unlink()
+            self.logger.warning("Removed the leftover of an index compaction that never committed")
+
     def _load_existing_data(self) -> None:
+        self._recover_interrupted_compaction()
         if not self.index_path.exists():
             return
         try:
@@ -202,6 +238,10 @@ class HybridStorage:
             self._saved_rows = loaded.ntotal
             self.logger.info(f"Loaded flat index with {loaded.ntotal} vectors")
             self._rebuild_id_mappings()
+            bad = [i for i in self.faiss_id_to_chunk_id if i >= loaded.ntotal]
+            if bad:   # e.g. a crash before the last save with auto_save off: those chunks have no vector on file
+                self.logger.warning(f"{len(bad)} chunks refer to rows beyond the {loaded.ntotal} rows of the index file; "
+                                    "they cannot be returned by searches until they are re-indexed")
         except Exception as e:  # corrupt / foreign file -> fresh index (src/storage.py:314-316)
             self.logger.warning(f"Could not load existing FAISS index: {e}")
             self._init_faiss()
@@ -566,15 +606,19 @@ class HybridStorage:
             self._saved_rows = n
         self.logger.info(f"Saved flat index ({n} vectors) to {self.index_path}")
 
+    def _crash_point(self, where: str) -> None:
+        """Test seam: tests replace this to simulate a crash between the steps of a journaled operation."""
+
     @staticmethod
     def _write_index_atomically(ix, path: str) -> None:
         """Whole-file write through a temporary sibling + ``os.replace``: readers (and a crash) see the old file or
-        the new one, never a torn one."""
+        the new one, never a torn one; the directory entry is made durable too."""
         tmp = path + ".tmp"
         fi.write_index(ix, tmp)
         with open(tmp, "rb") as f:
             os.fsync(f.fileno())
         os.replace(tmp, path)
+        _fsync_dir(Path(path).parent)
 
     def backup(self, backup_dir: str) -> None:
         dest = Path(backup_dir)
@@ -636,21 +680,29 @@ class HybridStorage:
                 lo, hi = part[0], part[-1] + 1
                 block = old.reconstruct_n(lo, hi - lo)
                 fresh.add(block[np.asarray(part) - lo])  # already normalised
-            self.chunk_id_to_faiss_id.clear()
-            self.faiss_id_to_chunk_id.clear()
+            fwd: Dict[str, int] = {}
+            rev: Dict[int, str] = {}
             updates = []
             for new_id, row in enumerate(live):
-                self.chunk_id_to_faiss_id[row["id"]] = new_id
-                self.faiss_id_to_chunk_id[new_id] = row["id"]
+                fwd[row["id"]] = new_id
+                rev[new_id] = row["id"]
                 updates.append((new_id, row["id"]))
-            # the renumbered ids only make sense with the compacted rows: put the new index file in place (atomically)
-            # before the SQLite commit, whatever auto_save says -- otherwise a crash, or auto_save=False, would pair
-            # the new ids with the old tombstoned file at the next start and searches would return the wrong chunks.
-            # (A crash between the two steps leaves new file + old ids: detected at load by ntotal != max id + 1 for a
-            # compaction that removed rows, and repaired by re-running optimize().)
+            # The renumbered ids only make sense with the compacted rows, whatever auto_save says.  Two files cannot
+            # change atomically together, so the step is journaled (see _recover_interrupted_compaction): compacted
+            # file beside the index, then ONE transaction with the new ids + a flag, then the rename, then the flag
+            # is cleared.  A crash at any point leaves a state the next initialize() completes or discards.
+            compact = str(self.index_path) + ".compact"
+            self._write_index_atomically(fresh, compact)
             cur.executemany("UPDATE chunks SET faiss_id = ? WHERE id = ?", updates)
-            self._write_index_atomically(fresh, str(self.index_path))
+            cur.execute("INSERT OR REPLACE INTO storage_meta (key, value) VALUES ('pending_compact', ?)", (str(len(live)),))
             self.db.commit()
+            self._crash_point("compaction committed, file not yet moved")
+            os.replace(compact, str(self.index_path))
+            _fsync_dir(self.index_path.parent)
+            cur.execute("DELETE FROM storage_meta WHERE key = 'pending_compact'")
+            self.db.commit()
+            self.chunk_id_to_faiss_id = fwd     # (in-memory maps change only once both files have)
+            self.faiss_id_to_chunk_id = rev
             self.faiss_index = fresh
             self._saved_rows = fresh.ntotal
             self.total_chunks = len(live)

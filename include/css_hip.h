@@ -113,7 +113,13 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * waits for the device: queries whose candidate band overflows are re-run exactly by
  * two launches that follow every cascade and return at once when there are none.
  * Rows appended by css_index_add_dev / css_index_add_synthetic on another stream are
- * ordered before the search by an event (no caller-side synchronisation needed). */
+ * ordered before the search by an event (no caller-side synchronisation needed); successive
+ * asynchronous adds on different streams are chained the same way.
+ * All searches of one index share one set of device workspaces: a search enqueued on a
+ * different stream than the previous one first waits (on the device, by an event) for that
+ * search to finish, so searches of ONE index execute one after the other whatever streams
+ * they are given -- use one index per concurrent stream (or shard) for overlap.  D_dev /
+ * I_dev belong to the caller: read them after synchronising with `stream` as usual. */
 /* Search path: CSS_SEARCH_AUTO (default) selects candidates with a reduced-precision scan
  * inside a rigorous error band and rescores them in fp32 where the multi-launch cascade
  * pays (one query: >= 1.2 M rows; batches always); CSS_SEARCH_EXACT_FP32 forms every score

@@ -321,6 +321,59 @@ class StorageCases:
         assert not (self.storage.index_path.parent / (self.storage.index_path.name + ".tmp")).exists()
         other.close()
 
+    def test_compaction_survives_a_crash_between_its_steps(self):
+        """optimize() changes two files (index rows, SQLite ids).  The step is journaled; a crash (a) after the
+        compacted file is written but before the ids are committed, and (b) after the commit but before the file is
+        moved into place, must both leave a data_dir in which ids and rows match at the next initialize() (ADVICE r2:
+        the old order paired compacted rows with stale sparse ids)."""
+        class Crash(Exception):
+            pass
+
+        q3, q2 = np.array([0.9, 0.1, 0.2, 0.3]), np.array([0.5, 0.6, 0.7, 0.8])
+
+        def check(n_rows):
+            other = HybridStorage(self.config)
+            other.initialize()
+            assert other.total_chunks == 2 and other.faiss_index.ntotal == n_rows
+            r3, r2 = other.search(q3), other.search(q2)
+            assert r3[0].chunk_id == "chunk_003" and abs(r3[0].similarity - 1.0) < 1e-5
+            assert r2[0].chunk_id == "chunk_002" and abs(r2[0].similarity - 1.0) < 1e-5
+            assert "chunk_001" not in [r.chunk_id for r in r3 + r2]
+            assert not Path(str(other.index_path) + ".compact").exists()
+            assert other.db.execute("SELECT COUNT(*) FROM storage_meta WHERE key = 'pending_compact'").fetchone()[0] == 0
+            other.close()
+
+        self.storage.initialize()
+        self.storage.add_chunks(self.chunks)
+        self.storage.save_index()
+        assert self.storage.delete_chunk("chunk_001")            # a tombstone in FRONT: every later id moves
+        # (a) crash before the transaction: simulated by making the id update fail after the file was written
+        real_write = HybridStorage._write_index_atomically
+
+        def write_then_die(ix, path):
+            real_write(ix, path)
+            if path.endswith(".compact"):
+                raise Crash()
+
+        self.storage._write_index_atomically = write_then_die
+        with pytest.raises(Crash):
+            self.storage.optimize()
+        self.storage.db.rollback()
+        assert Path(str(self.storage.index_path) + ".compact").exists()
+        check(3)                                                   # old file + old ids; the leftover is removed
+        # (b) crash after the commit, before the rename
+        del self.storage._write_index_atomically
+
+        def die(where):
+            raise Crash(where)
+
+        self.storage._crash_point = die
+        with pytest.raises(Crash):
+            self.storage.optimize()
+        assert Path(str(self.storage.index_path) + ".compact").exists()
+        check(2)                                                   # recovery moved the compacted file into place
+        check(2)                                                   # and the repaired state is stable
+
     def test_appended_rows_are_durable_before_the_header_counts_them(self):
         """save_index() appends new rows first and patches the header afterwards: a file cut off right behind the old
         rows + a stale header still loads as the old, complete index (trailing bytes are ignored)."""

@@ -496,6 +496,41 @@ def test_no_shadow_batches_match_oracle(n, nq, k, metric):
     ix.close()
 
 
+def test_no_shadow_large_batches_are_chunked_and_k_above_60_takes_the_mfma_scan():
+    """the split-operand candidate path sized its 32 KiB-per-query candidate buffers for the whole batch
+    (100 k queries = 3.3 GB) -- it now walks the batch in chunks of 4096 like the bf16 cascade; and shadow-less
+    batches with k = 61..64 (no room for the split scan's extra ranks) take the fp32-input MFMA scan, not 16-query
+    VALU sweeps."""
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    x = synth.rows(6000, 768, 311)
+    ix = IndexFlatIP(768)
+    ix.set_shadow(False)
+    ix.add(x, normalize=True)
+    ref = ko.FlatIndexOracle(768, 0)
+    ref.add(ko.normalize_rows(x))
+    q = synth.rows(4096 + 4096 + 130, 768, 312)            # two full chunks + a ragged one
+    qr = ko.normalize_rows(q)
+    nat.prof_reset()
+    nat.prof_enable(True)
+    D, I = ix.search(q, 10, normalize=True)
+    nat.prof_enable(False)
+    assert nat.prof_read("knn_split_cascade")[1] == 3
+    Dr, Ir = ref.search(qr, 10)
+    assert_topk_matches(D, I, Dr, Ir, ref.rescore64(qr, Ir), "no shadow, 8322 queries")
+    nat.prof_reset()
+    nat.prof_enable(True)
+    D, I = ix.search(q[:70], 63, normalize=True)
+    nat.prof_enable(False)
+    assert nat.prof_read("knn_scan_mfma")[1] == 1 and nat.prof_read("knn_scan_small")[1] == 0
+    Dr, Ir = ref.search(qr[:70], 63)
+    assert_topk_matches(D, I, Dr, Ir, ref.rescore64(qr[:70], Ir), "no shadow, k = 63")
+    nat.prof_reset()
+    ix.close()
+
+
 def test_no_shadow_band_beyond_the_kept_ranks_is_fixed_up():
     # 30 exact copies of the best row: the k + 4 ranks the split scan keeps all tie, the band cannot be shown
     # closed, the query is flagged and the exact fix-up returns the lowest ids
@@ -540,6 +575,49 @@ def test_search_right_behind_an_asynchronous_ingest_on_another_stream():
     rows /= (np.linalg.norm(rows, axis=1, keepdims=True) + 1e-8)
     d1, i1 = ix.search(rows, 1)
     assert i1[:, 0].tolist() == [n - 3, n - 2, n - 1] and np.all(np.abs(d1 - 1.0) < 1e-5)
+    ix.close()
+
+
+def test_searches_of_one_index_on_two_streams_do_not_share_workspaces_concurrently():
+    """All searches of an index use one set of device workspaces (padded queries, thresholds, candidate buffers,
+    partial lists).  css_index_search_dev only enqueues, so two searches given DIFFERENT streams used to be able
+    to run at the same time and overwrite each other's workspaces: the library now chains them with
+    an event.  Two different query batches are enqueued back to back on two streams, several rounds, in the
+    candidate path and in the exact path, and compared with the same searches run alone."""
+    import torch
+
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, d, k = 1_500_000, 768, 10
+    ix = IndexFlatIP(d)
+    ix.reserve(n)
+    ix.add_synthetic(n, seed=61, first_row=0, normalize=True)
+    dev = torch.device("cuda:0")
+    qa = torch.from_numpy(synth.rows(300, d, 62)).to(dev)
+    qb = torch.from_numpy(synth.rows(37, d, 63)).to(dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(q, stream):
+        D = torch.empty((q.shape[0], k), dtype=torch.float32, device=dev)
+        I = torch.empty((q.shape[0], k), dtype=torch.int64, device=dev)
+        ix.search_dev(q.data_ptr(), q.shape[0], k, D.data_ptr(), I.data_ptr(), stream=stream.cuda_stream, normalize=True)
+        return D, I
+
+    for mode in ("auto", "exact_fp32"):
+        ix.set_search_mode(mode)
+        torch.cuda.synchronize()
+        Da, Ia = run(qa, s1)
+        torch.cuda.synchronize()
+        Db, Ib = run(qb, s2)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            Da2, Ia2 = run(qa, s1)          # ~1-3 ms of device work, still running when the next call is enqueued
+            Db2, Ib2 = run(qb, s2)
+            Da3, Ia3 = run(qa, s1)
+            torch.cuda.synchronize()
+            assert torch.equal(Ia, Ia2) and torch.equal(Da, Da2), mode
+            assert torch.equal(Ib, Ib2) and torch.equal(Db, Db2), mode
+            assert torch.equal(Ia, Ia3) and torch.equal(Da, Da3), mode
     ix.close()
 
 

@@ -376,6 +376,9 @@ class EmbeddingGenerator:
         cap = self._gpu_capability
         info = dict(self._model_info_small(), batch_size=self.config.batch_size, use_gpu=self.config.use_gpu,
                     gpu_available=cap.can_use_gpu if cap else False)
+        problem = getattr(self.model, "tokenizer_problem", None)
+        if problem:   # real weights without their vocabulary: text is refused rather than hashed (build addition)
+            info["tokenizer_problem"] = problem
         if cap and cap.can_use_gpu:
             info["gpu_info"] = {
                 "gpu_count": cap.gpu_count,

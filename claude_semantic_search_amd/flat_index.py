@@ -210,11 +210,15 @@ def index_gpu_to_cpu(index: IndexFlat) -> IndexFlat:
     return index
 
 
-# On-disk format of faiss' IndexFlat ([from-knowledge], not
-# verifiable offline because faiss is not installed -- cross-compat untested):
-#   fourcc "IxFI" (IP) / "IxF2" (L2) | int32 d | int64 ntotal | int64 dummy (1<<20)
-#   | int64 dummy (1<<20) | uint8 is_trained | int32 metric_type
-#   | uint64 n_floats | n_floats * float32 (row-major)
+# On-disk format of faiss' IndexFlat as faiss/impl/index_write.cpp / index_read.cpp lay it out (SURVEY.md 8f rank 1;
+# [from knowledge of the public sources], not verifiable offline because faiss is not installed -- no file written by
+# real faiss has been read here; tests/test_storage_host.py assembles fixtures byte by byte from THIS description):
+#   fourcc  "IxFI" (inner product) | "IxF2" (L2) | "IxFl" (IndexFlat with the metric taken from the header)
+#   index header (write_index_header):  int32 d | int64 ntotal | int64 dummy (1 << 20) | int64 dummy (1 << 20)
+#                                       | uint8 is_trained | int32 metric_type (0 IP, 1 L2) [| float32 metric_arg if > 1]
+#   codes (WRITEXBVECTOR):              uint64 n_floats (= ntotal * d) | n_floats * float32, row-major
+# Readers ignore the two dummies; bytes behind the last row are ignored too (the append-on-save of HybridStorage
+# relies on that for crash safety).
 _FOURCC = {METRIC_INNER_PRODUCT: b"IxFI", METRIC_L2: b"IxF2"}
 _FAISS_METRIC = {METRIC_INNER_PRODUCT: 0, METRIC_L2: 1}
 
@@ -236,26 +240,39 @@ def write_index(index: IndexFlat, path: str, chunk_rows: int = 1 << 18) -> None:
 
 
 def read_index(path: str, device: int = 0, chunk_rows: int = 1 << 18) -> IndexFlat:
+    """``faiss.read_index`` for the flat indexes the reference writes (``src/storage.py:301-316``, ``:870-885``).
+    Anything else -- another index family, an untrained index, a header that contradicts itself, a file shorter
+    than its header promises -- raises ``RuntimeError`` (the reference then starts a fresh index, ``:314-316``)."""
+    def need(f, nbytes: int, what: str) -> bytes:
+        buf = f.read(nbytes)
+        if len(buf) != nbytes:
+            raise RuntimeError(f"truncated index file (in {what})")
+        return buf
+
     with open(path, "rb") as f:
-        fourcc = f.read(4)
-        metric = {v: k for k, v in _FOURCC.items()}.get(fourcc)
-        if metric is None:
-            raise RuntimeError(f"unsupported index file (fourcc {fourcc!r}); only IndexFlatIP/L2 are implemented")
-        (d,) = struct.unpack("<i", f.read(4))
-        (n,) = struct.unpack("<q", f.read(8))
-        f.read(16)
-        f.read(1)
-        f.read(4)
-        (nfl,) = struct.unpack("<Q", f.read(8))
+        fourcc = need(f, 4, "fourcc")
+        if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
+            raise RuntimeError(f"unsupported index file (fourcc {fourcc!r}); only IndexFlat (IxFI / IxF2 / IxFl) is implemented")
+        (d,) = struct.unpack("<i", need(f, 4, "d"))
+        (n,) = struct.unpack("<q", need(f, 8, "ntotal"))
+        need(f, 16, "header")                                   # two dummies (1 << 20 each): not interpreted, as in faiss
+        (trained,) = struct.unpack("<B", need(f, 1, "is_trained"))
+        (mtype,) = struct.unpack("<i", need(f, 4, "metric_type"))
+        if mtype not in (0, 1):
+            raise RuntimeError(f"unsupported metric_type {mtype} in index file (0 = inner product, 1 = L2)")
+        metric = METRIC_INNER_PRODUCT if mtype == 0 else METRIC_L2
+        if fourcc != b"IxFl" and fourcc != _FOURCC[metric]:
+            raise RuntimeError(f"corrupt index file: fourcc {fourcc!r} with metric_type {mtype}")
+        if trained != 1:
+            raise RuntimeError("corrupt index file: a flat index is always trained")
+        (nfl,) = struct.unpack("<Q", need(f, 8, "vector size"))
         if d <= 0 or n < 0 or nfl != n * d:
-            raise RuntimeError("corrupt index file")
+            raise RuntimeError(f"corrupt index file: d={d}, ntotal={n}, {nfl} floats")
         index = IndexFlat(d, metric, device)
         if n:
             index.reserve(n)
         for r0 in range(0, n, chunk_rows):
             m = min(chunk_rows, n - r0)
-            buf = f.read(m * d * 4)
-            if len(buf) != m * d * 4:
-                raise RuntimeError("truncated index file")
+            buf = need(f, m * d * 4, "rows")
             index.add(np.frombuffer(buf, dtype=np.float32).reshape(m, d))
     return index

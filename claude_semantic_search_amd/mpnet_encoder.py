@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import json
+import logging
 import os
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Union
@@ -30,17 +31,81 @@ DEFAULT_CFG = dict(num_layers=12, hidden=768, heads=12, ffn=3072, vocab=30527, m
                    pad_id=1, max_seq_len=384, ln_eps=1e-5)
 
 
+def _is_model_dir(c: Path) -> bool:
+    return c.is_dir() and ((c / "config.json").exists() or (c / "0_Transformer").is_dir())
+
+
+def _hub_snapshots(root: Path, name: str) -> List[Path]:
+    """Snapshot directories of the HF-hub cache layout ``root/models--<org>--<name>/snapshots/<rev>/`` -- where
+    sentence-transformers >= 3 (the reference pins >= 5, ``pyproject.toml``) leaves an auto-downloaded model when it
+    is given ``cache_folder`` (``src/embeddings.py:81-88``).  ``refs/main`` names the current revision; otherwise
+    the most recently modified snapshot wins."""
+    org, _, base = name.rpartition("/")
+    repos = [f"models--{org.replace('/', '--')}--{base}"] if org else [f"models--sentence-transformers--{base}", f"models--{base}"]
+    out: List[Path] = []
+    for repo in repos:
+        snaps = root / repo / "snapshots"
+        if not snaps.is_dir():
+            continue
+        ref = root / repo / "refs" / "main"
+        if ref.is_file():
+            cand = snaps / ref.read_text().strip()
+            if cand.is_dir():
+                out.append(cand)
+        out += sorted((d for d in snaps.iterdir() if d.is_dir()), key=lambda d: -d.stat().st_mtime)
+    return out
+
+
 def _find_model_dir(name_or_path: str, cache_folder: Optional[str]) -> Optional[Path]:
-    cands = [Path(name_or_path)]
+    """Where ``SentenceTransformer(name, cache_folder=...)`` would find the model without a network: the path itself,
+    the flat layouts ``<cache>/<name>`` and ``<cache>/sentence-transformers_<name>`` (what the reference's
+    ``scripts/model_setup.py:38-52`` writes), and the HF-hub layout under ``cache_folder``,
+    ``$SENTENCE_TRANSFORMERS_HOME``, ``$HF_HUB_CACHE`` / ``$HF_HOME/hub`` and ``~/.cache/huggingface/hub``."""
+    cands: List[Path] = [Path(name_or_path)]
+    base = name_or_path.rpartition("/")[2]
+    roots: List[Path] = []
     if cache_folder:
-        cands += [Path(cache_folder) / name_or_path, Path(cache_folder) / f"sentence-transformers_{name_or_path}"]
+        roots.append(Path(cache_folder))
     home = os.environ.get("SENTENCE_TRANSFORMERS_HOME")
     if home:
-        cands += [Path(home) / name_or_path, Path(home) / f"sentence-transformers_{name_or_path}"]
+        roots.append(Path(home))
+    hub_roots = list(roots)
+    if os.environ.get("HF_HUB_CACHE"):
+        hub_roots.append(Path(os.environ["HF_HUB_CACHE"]))
+    if os.environ.get("HF_HOME"):
+        hub_roots.append(Path(os.environ["HF_HOME"]) / "hub")
+    hub_roots.append(Path.home() / ".cache" / "huggingface" / "hub")
+    for r in roots:
+        cands += [r / name_or_path, r / base, r / f"sentence-transformers_{base}"]
+    for r in hub_roots:
+        cands += _hub_snapshots(r, name_or_path)
     for c in cands:
-        if c.is_dir() and ((c / "config.json").exists() or (c / "0_Transformer").is_dir()):
+        if _is_model_dir(c):
             return c
     return None
+
+
+def _tokenizer_files(model_dir: Path) -> Dict[str, object]:
+    """``vocab.txt`` and the lower-casing flag of a checkpoint directory.  Modern sentence-transformers layouts keep the
+    tokenizer files at the ROOT beside ``modules.json`` even when the weights sit in ``0_Transformer/``; older ones
+    keep everything in ``0_Transformer/``.  ``do_lower_case`` comes from ``tokenizer_config.json`` (all-mpnet-base-v2:
+    true -- MPNetTokenizer lower-cases; the ``do_lower_case: false`` of ``sentence_bert_config.json`` only says that
+    sentence-transformers does not lower-case a second time)."""
+    places = [model_dir, model_dir / "0_Transformer"]
+    vocab = next((p / "vocab.txt" for p in places if (p / "vocab.txt").is_file()), None)
+    lower = True
+    for p in places:
+        f = p / "tokenizer_config.json"
+        if f.is_file():
+            lower = bool(json.loads(f.read_text()).get("do_lower_case", True))
+            break
+    max_len = None
+    for p in places:
+        f = p / "sentence_bert_config.json"
+        if f.is_file():
+            max_len = json.loads(f.read_text()).get("max_seq_length")
+            break
+    return {"vocab": vocab, "lower": lower, "max_seq_length": max_len}
 
 
 def _load_state_dict(model_dir: Path) -> Dict[str, np.ndarray]:
@@ -92,14 +157,25 @@ class MpnetEncoder:
         nat.check(nat.lib().css_encoder_create(ctypes.byref(c), self._device_index, ctypes.byref(h)))
         self._h = h
         self.max_seq_length = cfg["max_seq_len"]
+        self.model_dir = model_dir
+        #: why text cannot be encoded (None when it can); surfaced by EmbeddingGenerator.get_model_info()
+        self.tokenizer_problem: Optional[str] = None
         if synthetic_seed is not None:
             nat.check(nat.lib().css_encoder_init_synthetic(self._h, ctypes.c_uint64(synthetic_seed)))
-            self.tokenizer = HashTokenizer(cfg["vocab"])
+            self.tokenizer = HashTokenizer(cfg["vocab"])   # synthetic weights: any deterministic text -> ids map will do
         else:
             self.load_state_dict(_load_state_dict(model_dir))
-            root = model_dir / "0_Transformer" if (model_dir / "0_Transformer").is_dir() else model_dir
-            vocab = root / "vocab.txt"
-            self.tokenizer = make_wordpiece(str(vocab)) if vocab.exists() else HashTokenizer(cfg["vocab"])
+            tk = _tokenizer_files(model_dir)
+            if tk["max_seq_length"]:
+                self.max_seq_length = min(int(tk["max_seq_length"]), cfg["max_seq_len"])
+            if tk["vocab"] is not None:
+                self.tokenizer = make_wordpiece(str(tk["vocab"]), lower=bool(tk["lower"]))
+            else:
+                # REAL weights with word ids from a hash would give plausible-looking garbage: refuse text instead
+                self.tokenizer = None
+                self.tokenizer_problem = (f"checkpoint {model_dir} has no vocab.txt (looked beside config.json and in "
+                                          "0_Transformer/): text cannot be tokenised for these weights")
+                logging.getLogger(__name__).warning(self.tokenizer_problem + "; encode_ids() still works")
 
     # -- lifetime -----------------------------------------------------------
     def close(self) -> None:
@@ -153,6 +229,8 @@ class MpnetEncoder:
         return int(self.cfg["hidden"])
 
     def tokenize(self, texts: Sequence[str]) -> List[List[int]]:
+        if self.tokenizer is None:
+            raise RuntimeError(self.tokenizer_problem or "no tokenizer")
         L = min(int(self.max_seq_length), int(self.cfg["max_seq_len"]))
         if hasattr(self.tokenizer, "encode_batch"):
             return self.tokenizer.encode_batch(texts, L)

@@ -190,3 +190,20 @@ def test_generate_embeddings_many_equals_per_file_calls(st):
             ref = g.generate_embeddings([Chunk(c.id, c.text, {}) for c in chunks])   # same sanitising per text
             assert np.array_equal(rows, ref)
             assert all(isinstance(c.embedding, np.ndarray) for c in chunks)
+
+
+def test_batch_size_policy_matches_the_committed_table():
+    """calculate_optimal_batch_size against a table computed from the reference's formula in exact
+    arithmetic (tests/golden/make_policy_goldens.py; src/gpu_utils.py:169-192), incl. the edges around 1 GB free and
+    the cap of 256 (64 for "mps")."""
+    import json
+    from pathlib import Path
+
+    from claude_semantic_search_amd.gpu_utils import calculate_optimal_batch_size
+
+    g = json.loads((Path(__file__).resolve().parent / "golden" / "batch_size_table.json").read_text())
+    assert len(g["rows"]) >= 50
+    for r in g["rows"]:
+        got = calculate_optimal_batch_size(r["free_gb"], embedding_dim=r["dim"], backend=r["backend"])
+        assert got == r["batch"], r
+    assert calculate_optimal_batch_size(2.0) == 256 and calculate_optimal_batch_size(0.5) == 8

@@ -288,6 +288,47 @@ def test_checkpoint_directory_loads_like_the_synthetic_init(tmp_path, prefix, su
         syn.close()
 
 
+def test_real_weights_without_vocabulary_refuse_text_and_root_level_vocab_is_used(tmp_path):
+    """a checkpoint directory without vocab.txt used to get the CRC32 HashTokenizer silently --
+    plausible-looking garbage embeddings.  Now: ids still encode, text raises, get_model_info() says why; with the
+    tokenizer files at the ROOT of a 0_Transformer/ layout (modern sentence-transformers) text works and honours
+    tokenizer_config.json's do_lower_case."""
+    import json
+
+    from oracle import mpnet_oracle as mo
+    from claude_semantic_search_amd.embeddings import EmbeddingConfig, EmbeddingGenerator
+
+    cfg = mo.MpnetCfg(num_layers=1)
+    w = mo.synth_weights(cfg, 3)
+    root = tmp_path / "all-mpnet-base-v2"
+    _write_checkpoint(root, cfg, w, prefix="0.auto_model.", subdir=True)
+    enc = MpnetEncoder("all-mpnet-base-v2", cache_folder=str(tmp_path), compute="fp32")
+    assert enc.tokenizer is None and "vocab.txt" in enc.tokenizer_problem
+    assert enc.encode_ids([[0, 9, 77, 2]]).shape == (1, 768)
+    with pytest.raises(RuntimeError, match="vocab.txt"):
+        enc.encode("fix the python error")
+    enc.close()
+    gen = EmbeddingGenerator(EmbeddingConfig(model_name="all-mpnet-base-v2", cache_dir=str(tmp_path), use_gpu=True))
+    gen.load_model()
+    assert "vocab.txt" in gen.get_model_info()["tokenizer_problem"]
+    # tokenizer files at the root, weights in 0_Transformer/
+    pieces = ["<s>", "<pad>", "</s>", "<unk>", "fix", "the", "python", "error", "Fix", "##s"]
+    (root / "vocab.txt").write_text("\n".join(pieces) + "\n")
+    (root / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": False}))
+    (root / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 128}))
+    enc = MpnetEncoder("all-mpnet-base-v2", cache_folder=str(tmp_path), compute="fp32")
+    assert enc.tokenizer_problem is None and enc.max_seq_length == 128
+    assert enc.tokenize(["Fix the python errors", "fix"]) == [[0, 8, 5, 6, 7, 9, 2], [0, 4, 2]]   # case kept
+    a = enc.encode(["Fix the python errors"])
+    ref = mo.encode(w, cfg, [[0, 8, 5, 6, 7, 9, 2]])
+    assert np.abs(a - ref).max() < 1e-4
+    enc.close()
+    (root / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True}))
+    enc = MpnetEncoder("all-mpnet-base-v2", cache_folder=str(tmp_path), compute="fp32")
+    assert enc.tokenize(["Fix"]) == [[0, 4, 2]]
+    enc.close()
+
+
 def test_incomplete_or_ambiguous_checkpoints_are_rejected(tmp_path):
     from oracle import mpnet_oracle as mo
     from claude_semantic_search_amd._native import CssError

@@ -54,3 +54,52 @@ def test_model_directory_discovery(tmp_path, monkeypatch):
     assert me._find_model_dir(str(tmp_path / "empty"), None) is None
     with pytest.raises(FileNotFoundError):
         me._load_state_dict(tmp_path / "empty")
+
+
+def test_hf_hub_cache_layout_is_found(tmp_path, monkeypatch):
+    """sentence-transformers >= 3 (the reference pins >= 5) downloads into the HF-hub layout under cache_folder:
+    models--sentence-transformers--<name>/snapshots/<rev>/ (src/embeddings.py:81-88 passes cache_folder and sets
+    SENTENCE_TRANSFORMERS_HOME)."""
+    monkeypatch.delenv("SENTENCE_TRANSFORMERS_HOME", raising=False)
+    monkeypatch.delenv("HF_HOME", raising=False)
+    monkeypatch.delenv("HF_HUB_CACHE", raising=False)
+    monkeypatch.setenv("HOME", str(tmp_path / "nohome"))
+    repo = tmp_path / "cache" / "models--sentence-transformers--all-mpnet-base-v2"
+    old, new = repo / "snapshots" / "aaaa", repo / "snapshots" / "bbbb"
+    _fake_dir(old)
+    _fake_dir(new)
+    (repo / "refs").mkdir()
+    (repo / "refs" / "main").write_text("bbbb\n")
+    for name in ("all-mpnet-base-v2", "sentence-transformers/all-mpnet-base-v2"):
+        assert me._find_model_dir(name, str(tmp_path / "cache")) == new
+    (repo / "refs" / "main").unlink()                      # no ref file: the newest snapshot
+    import os
+    os.utime(old, (2_000_000_000, 2_000_000_000))
+    assert me._find_model_dir("all-mpnet-base-v2", str(tmp_path / "cache")) == old
+    # another organisation: models--<org>--<name>
+    _fake_dir(tmp_path / "cache" / "models--acme--tiny-mpnet" / "snapshots" / "r1")
+    assert me._find_model_dir("acme/tiny-mpnet", str(tmp_path / "cache")).name == "r1"
+    assert me._find_model_dir("acme/other", str(tmp_path / "cache")) is None
+    # through the environment the reference sets, and through HF_HOME
+    monkeypatch.setenv("SENTENCE_TRANSFORMERS_HOME", str(tmp_path / "cache"))
+    assert me._find_model_dir("all-mpnet-base-v2", None) == old
+    monkeypatch.delenv("SENTENCE_TRANSFORMERS_HOME")
+    hub = tmp_path / "hf" / "hub" / "models--sentence-transformers--all-mpnet-base-v2" / "snapshots" / "zz"
+    _fake_dir(hub)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    assert me._find_model_dir("all-mpnet-base-v2", None) == hub
+
+
+def test_tokenizer_files_root_level_vocab_and_lowercase_flag(tmp_path):
+    """Modern sentence-transformers directories keep vocab.txt / tokenizer_config.json at the root while older ones keep
+    them with the weights in 0_Transformer/; do_lower_case is the TOKENIZER's flag."""
+    d = tmp_path / "m"
+    _fake_dir(d, sub=True)
+    assert me._tokenizer_files(d) == {"vocab": None, "lower": True, "max_seq_length": None}
+    (d / "0_Transformer" / "vocab.txt").write_text("<s>\n<pad>\n</s>\n<unk>\n")
+    assert me._tokenizer_files(d)["vocab"] == d / "0_Transformer" / "vocab.txt"
+    (d / "vocab.txt").write_text("<s>\n<pad>\n</s>\n<unk>\nroot\n")       # the root wins when both exist
+    (d / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": False}))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 256, "do_lower_case": True}))
+    got = me._tokenizer_files(d)
+    assert got == {"vocab": d / "vocab.txt", "lower": False, "max_seq_length": 256}

@@ -50,7 +50,7 @@ FP32_MFMA_PEAK_TF = 157.3    # dense fp32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--only-encoder", action="store_true", help="development aid: run just the encoder leg")
     ap.add_argument("--enc-fixed-only", action="store_true", help="encoder leg: only the fixed batch x len shape (counter passes)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling line of the 10 M-row index")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_baseline_knn(args, log):
@@ -389,8 +389,75 @@ def timed_steps(step, fence, nsteps):
     return time.perf_counter() - t0
 
 
-def main():
-    args = parse_args()
+class HipPlatform:
+    """What main() needs from the machine: the device, the process group, the fences and the sharded index.  The
+    product platform is one HIP device per rank with RCCL ("nccl") between them.  tests/bench_rehearsal.py
+    substitutes a CPU platform (gloo + oracle-backed doubles that live under tests/) to drive THIS main() through
+    its N > 1 control flow without a GPU; bench.py itself never imports those doubles."""
+    name = "hip"
+
+    def __init__(self, local_rank: int):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+        # CSS_BENCH_ONE_GPU=1 (rehearsal of the N > 1 path on a one-GPU box): every rank uses cuda:0 over gloo
+        self.one_gpu = os.environ.get("CSS_BENCH_ONE_GPU") == "1"
+        self.local_rank = 0 if self.one_gpu else local_rank
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.reduce_dev = torch.device("cpu") if self.one_gpu else self.dev   # where small all-reduce tensors live
+
+    def init_group(self):
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if self.one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=self.dev)
+
+    def barrier(self):
+        import torch.distributed as dist
+
+        if self.one_gpu:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[self.local_rank])   # (RCCL: name the device, or the barrier guesses it from the rank)
+
+    def sync(self):
+        import torch
+
+        torch.cuda.synchronize()
+
+    def stream(self) -> int:
+        import torch
+
+        return torch.cuda.current_stream().cuda_stream
+
+    def make_sharded(self, dim: int):
+        from claude_semantic_search_amd.sharded import ShardedFlatIndex
+
+        return ShardedFlatIndex(dim, 0, device_index=self.local_rank)
+
+
+def main(argv=None, platform_factory=None):
+    """``platform_factory(local_rank)``: see HipPlatform (tests only pass another one)."""
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        _main(argv, platform_factory)
+    except SystemExit:
+        raise
+    except BaseException as ex:   # a failure on ANY rank must fail the job, and say which rank it was
+        import traceback
+
+        traceback.print_exc()
+        print(f"bench.py: rank {rank} failed: {ex!r}", file=sys.stderr, flush=True)
+        sys.exit(1)
+
+
+def _main(argv, platform_factory):
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,6 +465,7 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     def log(msg):
         if rank == 0:
@@ -409,48 +477,38 @@ def main():
 
     from claude_semantic_search_amd import _native as nat
     from claude_semantic_search_amd import synth
-    from claude_semantic_search_amd.sharded import ShardedFlatIndex
 
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
-    # CSS_BENCH_ONE_GPU=1 (rehearsal of the N > 1 path on a one-GPU box): every rank uses cuda:0 over gloo
-    one_gpu = os.environ.get("CSS_BENCH_ONE_GPU") == "1"
-    if one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    plat = (platform_factory or HipPlatform)(local_rank)
+    dev = plat.dev
+    hip = plat.name == "hip"
     if args.only_encoder:
         print(json.dumps({"encode": bench_encoder(args, dev, log)}), flush=True)
         return
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        plat.init_group()
 
     def fence():
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            plat.barrier()
+        plat.sync()
 
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        t = torch.tensor([x], dtype=torch.float64, device=plat.reduce_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     # ---- build this rank's shard in HBM (rows generated on the device) -------
     # weak scaling: args.rows rows PER GPU of one virtual index of args.rows * world rows (N = 8: 80 M x 768)
     rows_total = args.rows * world
-    stream = torch.cuda.current_stream().cuda_stream
-    sh = ShardedFlatIndex(args.dim, 0, device_index=local_rank)
+    stream = plat.stream()
+    sh = plat.make_sharded(args.dim)
     t0 = time.perf_counter()
     sh.add_synthetic_global(rows_total, seed=4, normalize=True, stream=stream)
     index = sh.local
     shard = index.ntotal
-    torch.cuda.synchronize()
+    plat.sync()
     log(f"rank0 shard: {shard} of {rows_total} rows x {args.dim} ({shard * args.dim * 4 / 1e9:.2f} GB fp32) generated in "
         f"{time.perf_counter() - t0:.2f}s")
 
@@ -531,7 +589,7 @@ def main():
     extra = {}
     D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
     I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
-    if not args.no_extra:
+    if not args.no_extra and hip:
         D1 = torch.empty((1, 100), dtype=torch.float32, device=dev)
         I1 = torch.empty((1, 100), dtype=torch.int64, device=dev)
         for kq, Dq, Iq in ((10, D[:1], I[:1]), (100, D1, I1)):
@@ -646,7 +704,7 @@ def main():
     strong = None
     if world > 1 and not args.no_strong:
         sh.local.close()
-        sh2 = ShardedFlatIndex(args.dim, 0, device_index=local_rank)
+        sh2 = plat.make_sharded(args.dim)
         sh2.add_synthetic_global(args.rows, seed=4, normalize=True, stream=stream)
         for _ in range(max(2, args.warmup)):
             sh2.search_tensors(q, args.k, normalize=True)
@@ -662,7 +720,7 @@ def main():
         cpu = cpu_baseline_knn(args, log)
 
     # ---- clustered rows: how much of the throughput survives dense candidate bands (flagged fraction) ----
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and hip:
         try:
             extra["clustered_1M"] = bench_clustered(args, dev, stream, log)
         except Exception as ex_:   # an extra: never fail the bench line over it
@@ -676,7 +734,7 @@ def main():
             # encoder: replicas only (weights replicated, one batch per rank, no collective in the path)
             args.no_cpu_baseline = True
             enc = bench_encoder(args, dev, (lambda m: None) if rank else log)
-            t = torch.tensor([enc["chunks_per_s"], enc["ms_per_batch"]], dtype=torch.float64, device="cpu" if one_gpu else dev)
+            t = torch.tensor([enc["chunks_per_s"], enc["ms_per_batch"]], dtype=torch.float64, device=plat.reduce_dev)
             tsum = t.clone()
             dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -695,7 +753,7 @@ def main():
             cpu["encode"] = enc["cpu_baseline"]
 
     if world > 1:
-        dist.barrier()
+        plat.barrier()
     if rank == 0:
         cfg_name = ("BASELINE configs[3]: 10Mx768 index on 1 MI355X, 1k-query batch top-10" if world == 1 and args.rows == 10_000_000
                     else f"BASELINE configs[4] shape: {rows_total}x{args.dim} index sharded over {world} MI355X "
@@ -714,7 +772,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (index, queries and returned scores fp32; candidate selection by a bf16 MFMA scan with a "
                      "rigorous error band, candidates rescored in fp32)",
-            "data": "synthetic",
+            "data": "synthetic" if hip else f"synthetic, on the {plat.name} platform (control-flow rehearsal: NOT a measurement)",
             "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
                                    f"top-{args.k}, {args.rows} rows per GPU",
                        "rows_total": rows_total, "rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k,

@@ -27,6 +27,9 @@ class _FakeLocal:
     def reserve(self, n):
         pass
 
+    def close(self):
+        pass
+
     def add(self, x, normalize=False):
         self.o.add(self.ko.normalize_rows(x) if normalize else x)
 

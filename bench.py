@@ -100,15 +100,104 @@ def cpu_baseline_knn(args, log):
     full = t * (args.rows / rows)
     gflops = 2.0 * rows * args.dim * args.nq / t / 1e9
     log(f"cpu baseline: {rows} rows x {args.nq} queries in {t:.2f}s ({gflops:.0f} GFLOP/s, BLAS threads={blas_threads})")
+    # The reference's REAL call shape (src/storage.py:429-436: one query, k' = min(10 * top_k, ntotal) = 100): faiss
+    # scans the rows for a single query on one thread.  One thread of the C oracle over a bounded prefix, scaled.
+    ko.set_threads(1)
+    rows1 = min(rows, 1_000_000)
+    o1 = ko.FlatIndexOracle(args.dim, 0)
+    o1._xb = x[:rows1]                                    # (no copy; the oracle only reads it)
+    o1.search(q[:1], 100)
+    reps1 = 3
+    t0 = time.perf_counter()
+    for i in range(reps1):
+        o1.search(q[i:i + 1], 100)
+    t1 = (time.perf_counter() - t0) / reps1
+    full1 = t1 * (args.rows / rows1)
+    ko.set_threads(min(os.cpu_count() or 1, 64))
+    log(f"cpu baseline, one query on one thread: {rows1} rows in {t1 * 1e3:.0f} ms -> {full1 * 1e3:.0f} ms per query at {args.rows} rows")
     return {
         "value": args.nq / full,
         "unit": "queries/s",
         "cores": int(blas_threads),
         "kind": "port",
         "achieved_GFLOPs": gflops,
-        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, blocked SGEMM (numpy BLAS, {blas_threads} threads) "
+        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, blocked SGEMM (numpy BLAS, {blas_threads} threads; "
+                  f"limited by that BLAS build, far below what these cores can do in SGEMM) "
                   f"+ heap fold in C/OpenMP (oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
+        "nq1_single_thread": {
+            "value": 1.0 / full1, "unit": "queries/s", "cores": 1, "kind": "port", "latency_ms": full1 * 1e3, "k": 100,
+            "scan_GBps": rows1 * args.dim * 4 / t1 / 1e9,
+            "sample": f"one query, top-100 (the reference's k' for top_k = 10), first {rows1} of {args.rows} rows, scalar C scan on "
+                      f"1 thread (oracle.knn_oracle.FlatIndexOracle.search), mean of {reps1} queries, time scaled "
+                      f"x{args.rows / rows1:.1f} (extrapolated)"},
     }
+
+
+# what the rocprofv3 FETCH_SIZE / WRITE_SIZE counters behind every "traffic" field measure (MI355X_MICROARCH.md)
+TRAFFIC_KIND = "L2-miss bytes (fabric side: HBM + Infinity-Cache hits), rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes"
+
+
+def bench_query_e2e(args, dev, index, stream, log):
+    """The reference's user-visible query (src/cli.py:232-251): generate_single_embedding(text) -> search with
+    k' = min(10 * top_k, ntotal) = 100 (src/storage.py:429-436).  Encoder = the tiny-batch hipGraph path, search = the
+    single-query cascade over the resident index.  Two chains: device resident (ids on the device, one stream, one
+    synchronisation at the end) and the host API the reference's call sites use (numpy in / numpy out per call)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+
+    enc = MpnetEncoder(synthetic_seed=1, compute="bf16", device=dev.index or 0)
+    ntok, kq = 16, 100                      # a one-line query: <s> + 14 word pieces + </s>
+    ids_h = np.concatenate([[0], 4 + (np.arange(ntok - 2) * 7919) % 30000, [2]]).astype(np.int32)
+    cu_h = np.array([0, ntok], dtype=np.int32)
+    ids, cu = torch.from_numpy(ids_h).to(dev), torch.from_numpy(cu_h).to(dev)
+    emb = torch.empty((1, 768), dtype=torch.float32, device=dev)
+    D = torch.empty((1, kq), dtype=torch.float32, device=dev)
+    I = torch.empty((1, kq), dtype=torch.int64, device=dev)
+
+    def encode_dev():
+        nat.check(nat.lib().css_encoder_forward_dev(enc._h, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(cu.data_ptr()), 1,
+                                                    ntok, ntok, 1, ctypes.c_void_p(emb.data_ptr()), ctypes.c_void_p(stream)))
+
+    def search_dev():
+        index.search_dev(emb.data_ptr(), 1, kq, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+
+    def timed(fn, reps):
+        for _ in range(4):                  # (a tiny-batch shape is captured into a hipGraph on its second use)
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+            torch.cuda.synchronize()        # per-query latency: every query waits for its answer
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    reps = 30
+    enc_ms, search_ms = timed(encode_dev, reps), timed(search_dev, reps)
+    both_ms = timed(lambda: (encode_dev(), search_dev()), reps)
+    q_h = None
+
+    def host_chain():
+        nonlocal q_h
+        q_h = enc.encode_ids([ids_h.tolist()])             # numpy [1, 768] back on the host
+        return index.search(q_h, kq, normalize=True)
+
+    host_ms = timed(host_chain, 10)
+    host_enc_ms = timed(lambda: enc.encode_ids([ids_h.tolist()]), 10)
+    enc.close()
+    out = {"encode_ms": enc_ms, "search_ms": search_ms, "sum_ms": enc_ms + search_ms, "chained_ms": both_ms,
+           "host_api_chain_ms": host_ms, "host_api_encode_ms": host_enc_ms, "host_api_search_ms": host_ms - host_enc_ms,
+           "query_tokens": ntok, "k": kq, "rows": int(index.ntotal),
+           "note": "encode = hipGraph replay of the tiny-batch encoder path, search = single-query coarse sweep + exact "
+                   "rescoring (k' = 100, the reference's call shape for top_k = 10); device-resident numbers synchronise "
+                   "once per query; host_api_* are the numpy-in / numpy-out calls of the reference's own call sites "
+                   "(PCIe copies and two synchronisations included)"}
+    log(f"query e2e: encode {enc_ms:.2f} ms + search {search_ms:.2f} ms (chained {both_ms:.2f} ms; host API {host_ms:.2f} ms)")
+    return out
 
 
 def encoder_flops(lengths, layers=12):
@@ -117,7 +206,7 @@ def encoder_flops(lengths, layers=12):
 
 
 def pmc_traffic(kernel_prefix, workload):
-    """HBM bytes per launch of `kernel_prefix` from the newest committed rocprofv3 PMC summary
+    """L2-miss (fabric-side: HBM + Infinity-Cache hits, MI355X_MICROARCH.md) bytes per launch of `kernel_prefix` from the newest committed rocprofv3 PMC summary
     (profiles/r*_pmc_hbm_traffic.json, made by tools/pmc_summarise.py from separate --pmc FETCH_SIZE /
     --pmc WRITE_SIZE passes over this same command); None when no summary matches this workload."""
     import glob
@@ -135,7 +224,7 @@ def pmc_traffic(kernel_prefix, workload):
 
 
 def pmc_traffic_encoder(workload):
-    """HBM-side bytes of ONE encoder forward: every kernel's bytes summed over a profiled run of the fixed shape
+    """L2-miss (fabric-side, includes Infinity-Cache hits) bytes of ONE encoder forward: every kernel's bytes summed over a profiled run of the fixed shape
     (profiles/r*_pmc_hbm_traffic_encoder.json), divided by the number of forwards (= launches of the embedding kernel)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_encoder.json")), reverse=True):
@@ -230,6 +319,7 @@ def bench_encoder(args, dev, log):
     if tr:
         res["roofline"]["traffic"] = tr["bytes_per_forward"]
         res["roofline"]["traffic_source"] = tr["source"]
+        res["roofline"]["traffic_kind"] = TRAFFIC_KIND
     log(f"encoder: {B}x{L} in {dt * 1e3:.2f} ms -> {B / dt:.0f} chunks/s, {fl / dt / 1e12:.0f} TFLOP/s")
     if not args.no_cpu_baseline:
         from oracle import mpnet_oracle as mo
@@ -582,6 +672,7 @@ def _main(argv, platform_factory):
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
+            roofline["traffic_kind"] = TRAFFIC_KIND
             roofline["algorithmic_bytes_per_launch"] = sweep_bytes
     nat.prof_reset()
 
@@ -630,6 +721,15 @@ def _main(argv, platform_factory):
                 roofline["nq1_k10"] = rec
             extra[f"nq1_k{kq}"] = rec
             nat.prof_reset()
+
+        # ---- the reference's user-visible query: encode one query + search it (k' = 100) ----
+        if world == 1 and not args.no_encoder:
+            try:
+                extra["query_e2e"] = bench_query_e2e(args, dev, index, stream, log)
+                if roofline is not None:
+                    roofline["query_e2e"] = extra["query_e2e"]
+            except Exception as ex_:   # an extra: never fail the bench line over it
+                extra["query_e2e"] = {"error": repr(ex_)}
 
         # ---- masked search (filter / tombstone push-down), half of the rows allowed ----
         words = (shard + 31) // 32

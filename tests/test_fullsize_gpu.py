@@ -162,3 +162,56 @@ def test_10m_bench_queries_match_the_cpu_oracle(big_index, bench_queries_and_ora
             assert_topk_matches(D4, I4, Dr[8:12], Ir[8:12], D64[8:12], f"10M 4 queries [{mode}]")
     finally:
         big_index.set_search_mode("auto")
+
+
+def test_config0_ten_thousand_chunks_encode_index_search_chain():
+    """BASELINE configs[0] at its stated size: 10 000 synthetic chunks with the chunker's length
+    mix (chars ~ U[100, 2000] -> L = clip(round(chars / 4) + 2, 2, 384), ~25 % at the 384 cap), encoded by the HIP
+    encoder (12 layers, bf16 product mode, batches of 256, length-sorted), added to the HIP flat-IP index, 100 queries
+    = rows {0, 100, ...}.  Parity in two independent halves (SURVEY "hard parts" (ii)): (a) a sample of the
+    embeddings against the fp32 CPU oracle encoder, cos >= 1 - 1e-3; (b) the HIP top-10 against the CPU oracle kNN run
+    on the HIP embedding matrix itself -- same ids outside fp64 near-ties, scores within 1e-3."""
+    from knn_checks import assert_topk_matches
+    from oracle import knn_oracle as ko
+    from oracle import mpnet_oracle as mo
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+    from claude_semantic_search_amd.mpnet_encoder import MpnetEncoder
+
+    n, bs = 10_000, 256
+    cfg = mo.MpnetCfg()
+    chars = 100 + synth.uint(1, np.arange(n, dtype=np.uint64), 0, 1901)
+    lens = np.clip(np.round(chars / 4).astype(np.int64) + 2, 2, 384)
+    assert 0.2 < (lens == 384).mean() < 0.3 and 230 < lens.mean() < 270
+    batch = mo.synth_batch(cfg, lens.tolist(), seed=1)
+    enc = MpnetEncoder(synthetic_seed=1, compute="bf16")
+    emb = np.empty((n, 768), dtype=np.float32)
+    order = np.argsort(-lens, kind="stable")
+    for s in range(0, n, bs):
+        idx = order[s:s + bs]
+        emb[idx] = enc.encode_ids([batch[i] for i in idx])
+    enc.close()
+    assert np.isfinite(emb).all() and np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-3
+    # (a) encoder parity on a sample spread over lengths and batches (incl. the shortest, the longest, first, last)
+    sample = sorted(set([0, n - 1, int(order[0]), int(order[-1])] + list(range(37, n, n // 28))))[:32]
+    w = mo.synth_weights(cfg, 1)
+    ref = mo.encode(w, cfg, [batch[i] for i in sample])
+    cos = (emb[sample] * ref).sum(1)
+    assert cos.min() > 1 - 1e-3, cos
+    # (b) kNN parity on the HIP embedding matrix
+    ix = IndexFlatIP(768)
+    ix.add(emb, normalize=True)
+    q = emb[::100]
+    o = ko.FlatIndexOracle(768, 0)
+    xr, qr = ko.normalize_rows(emb), ko.normalize_rows(q)
+    o.add(xr)
+    for k in (10, 100):
+        Dr1, Ir1 = o.search(qr, k + 1)                     # rank k + 1 too: the last slot may tie with it
+        D641 = o.rescore64(qr, Ir1)
+        Dr, Ir, D64 = Dr1[:, :k], Ir1[:, :k], D641[:, :k]
+        for mode in ("auto", "coarse", "exact_fp32"):
+            ix.set_search_mode(mode)
+            Dh, Ih = ix.search(q, k, normalize=True)
+            assert_topk_matches(Dh, Ih, Dr, Ir, D64, f"config0 k={k} [{mode}]", D64_next=D641[:, k])
+            assert (Ih[:, 0] == np.arange(0, n, 100)).all() and np.abs(Dh[:, 0] - 1).max() < 1e-5
+    ix.close()

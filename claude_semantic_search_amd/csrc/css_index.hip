@@ -74,6 +74,14 @@ struct css_index {
     // device-side exact fix-up of flagged queries (k_scan_small<FIX>): one global list + lock per query
     float* fix_s = nullptr;   uint32_t* fix_i = nullptr; size_t fix_cap = 0;    // entries [nq_pad][k]
     int* fix_lock = nullptr;  size_t fix_lock_cap = 0;
+    // second coarse pass over flagged queries (launch_scan_coarse): up to kF2Max slots with CZ_CAP2 candidates each
+    unsigned short* qh2 = nullptr; size_t qh2_cap = 0;   // bf16 rows of the flagged queries
+    float* thr2 = nullptr;    size_t thr2_cap = 0;
+    int* cand_n2 = nullptr;   size_t cand_n2_cap = 0;
+    float* cand_s2 = nullptr; size_t cand_s2_cap = 0;
+    uint32_t* cand_i2 = nullptr; size_t cand_i2_cap = 0;
+    int* flagB = nullptr;     size_t flagB_cap = 0;      // [nq_pad] list | [1] count: queries left to the exact sweep
+    const int* last_nswept = nullptr;                    // device counter behind css_index_last_swept
     // rows written by css_index_add_dev / _add_synthetic on the CALLER's stream: searches, reallocation and
     // export wait for this event before touching rows, norms or maxn2
     hipEvent_t ingest_ev = nullptr;
@@ -1243,6 +1251,7 @@ struct KnnEnv {
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
     int loop8 = 1;        // CSS_KNN_LOOP=old: the round-1 main loop (k_scan_coarse) instead of k_scan_coarse8 (A/B runs)
+    int pass2 = 1;        // CSS_KNN_PASS2=0: flagged queries go straight to the exact fp32 sweep (A/B runs)
 };
 const KnnEnv& knn_env() {
     static const KnnEnv env = [] {
@@ -1257,6 +1266,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
         if (const char* m = getenv("CSS_KNN_LOOP")) e.loop8 = std::string(m) == "old" ? 0 : 1;
+        if (const char* m = getenv("CSS_KNN_PASS2")) e.pass2 = m[0] == '0' ? 0 : 1;
         return e;
     }();
     return env;
@@ -1377,6 +1387,7 @@ int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
     if ((rc = grow(&ix->cthr, &ix->cthr_cap, nq_pad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, nq_pad)) != CSS_OK) return rc;
     ix->last_nflag = nullptr;
+    ix->last_nswept = nullptr;
     if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 1)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
@@ -1395,6 +1406,9 @@ int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
     return CSS_OK;
 }
 
+// second coarse pass over flagged queries: slots (query rows) and candidates per slot
+constexpr int kF2Max = 1024;
+constexpr int CZ_CAP2 = 32768;
 // largest k the MFMA kernels' LDS lists hold next to their staging buffers
 constexpr int kMfmaMaxK = 64;
 // extra ranks the split-operand candidate scan keeps beyond k (the band must close inside them, else the
@@ -1445,6 +1459,23 @@ int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_
 // (k_scan_mfma_split: h.h + h.l + l.h, error <= kSplitEps ||q|| max||x||), the scan keeps k + kSplitExtra
 // ranks per query, and k_coarse_select<FINAL> rescores the band in fp32 exactly as the bf16 cascade does.  A
 // query whose band does not close inside the kept ranks is flagged and re-run by the device-side fix-up.
+// After the last stage of a candidate scan: band cut + flagging (one block per query), exact rescoring of the bands
+// (CZ_PARTS work items per query over a fixed grid), sort by exact score + output (one block per query).
+constexpr int kRescoreGrid = 4096;
+int launch_final_select(css_index* ix, int nq, int k, float eps_rel, int l2, int closed_n, const float* qpad, const float* qnorm2,
+                        int* gthr, int* flags, int* nflag, int* flag_list, float* D_dev, int64_t* I_dev, float* thr2,
+                        unsigned short* qh2, int f2, hipStream_t st) {
+    hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr, flags,
+                       nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, ix->fix_s, ix->fix_i, ix->fix_lock);
+    hipLaunchKernelGGL(k_rescore_parts<false>, dim3(std::min(kRescoreGrid, nq * CZ_PARTS)), dim3(256), 0, st, ix->cand_s,
+                       ix->cand_i, ix->cand_n, CZ_CAP, nq, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, l2, qpad,
+                       ix->xb, ix->dpad);
+    hipLaunchKernelGGL(k_coarse_final, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, flags, qnorm2, ix->maxn2,
+                       eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
 template <int METRIC>
 int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
                               hipStream_t st) {
@@ -1475,6 +1506,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
     int* flag_list = ix->cflags + nq_pad;
     int* nflag = ix->cflags + 2 * nq_pad;
     ix->last_nflag = nflag;
+    ix->last_nswept = nflag;
     if (nq_pad > nq)
         CSS_HIP_TRY(hipMemsetAsync(qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, gthr, nq_pad, host_f2key(-INFINITY));
@@ -1505,11 +1537,9 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
     hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, gthr,
                        qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
                        ix->cand_n);
-    hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
-                       flags, nflag, flag_list, qnorm2, ix->maxn2, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, k,
-                       qpad, ix->xb, ix->dpad, ix->id_base, D_dev, I_dev, kp, gthr, ix->fix_s, ix->fix_i,
-                       ix->fix_lock);
-    CSS_LAUNCH_CHECK();
+    if ((rc = launch_final_select(ix, nq, k, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
+                                  flag_list, D_dev, I_dev, nullptr, nullptr, 0, st)) != CSS_OK)
+        return rc;
     return launch_fixup(ix, qpad, nq, k, gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
                         sg, st);
 }
@@ -1567,6 +1597,30 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     int* flag_list = ix->cflags + nq_pad;
     int* nflag = ix->cflags + 2 * nq_pad;
     ix->last_nflag = nflag;
+    // Second pass (batches on indexes whose rows can overflow a 4096-slot buffer at all): flagged queries -- band or
+    // buffer overflow: dense clusters, duplicate floods -- are scanned once more, together, against the threshold the
+    // exact scores of their buffered candidates give (k_coarse_select<true>), into CZ_CAP2-slot buffers; only what
+    // overflows those too goes on to the exact fp32 sweep.  Round 2 sent every flagged query to that sweep (8 queries
+    // per pass over the fp32 rows): 22 flagged of 1000 queries cost 2.9 ms of a 7 ms batch at 1 M clustered rows.
+    const bool pass2 = !sweep && env.pass2 && env.loop8 && env.mfma_shape == 16 && ix->dpad % 128 == 0 && ix->ntotal > CZ_CAP;
+    const int f2 = pass2 ? std::min(nq_pad, kF2Max) : 0;   // (a multiple of CZ_T)
+    int* flag_listB = nullptr;
+    int* nflagB = nullptr;
+    ix->last_nswept = nflag;
+    if (pass2) {
+        const size_t qh2_before = ix->qh2_cap;
+        if ((rc = grow(&ix->qh2, &ix->qh2_cap, (size_t)f2 * ix->dpad)) != CSS_OK) return rc;
+        // slots beyond the flagged count are scanned with a +inf threshold; their rows must still be finite numbers
+        if (ix->qh2_cap != qh2_before) CSS_HIP_TRY(hipMemsetAsync(ix->qh2, 0, ix->qh2_cap * sizeof(unsigned short), st));
+        if ((rc = grow(&ix->thr2, &ix->thr2_cap, (size_t)f2)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->cand_n2, &ix->cand_n2_cap, (size_t)f2)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->cand_s2, &ix->cand_s2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->cand_i2, &ix->cand_i2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->flagB, &ix->flagB_cap, (size_t)nq_pad + 1)) != CSS_OK) return rc;
+        flag_listB = ix->flagB;
+        nflagB = ix->flagB + nq_pad;
+        ix->last_nswept = nflagB;
+    }
 
     // cascade schedule: a nested, uniformly strided sample of row tiles.  Stage 0 reads every s-th tile (at most 15
     // tiles: it keeps every score, 3840 of the 4096 slots), every later stage the tiles at a stride `ratio` times
@@ -1604,11 +1658,13 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
         hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T));
+        if (pass2)
+            hipLaunchKernelGGL(k_coarse_init2, dim3((f2 + 255) / 256), dim3(256), 0, st, ix->cand_n2, ix->thr2, nflagB, f2);
         CSS_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int);
+                            int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int, const int*);
     // (the DBG instantiations honour CSS_KNN_DBG; the product kernels carry no timing switches)
     // v_mfma_f32_16x16x32_bf16 by default: same cycles per flop and LDS traffic as 32x32x16, but the chip holds a
     // higher clock under it (measured in one session: main stage 11.1 ms vs 12.1 ms); CSS_KNN_MFMA=32 for A/B runs
@@ -1653,22 +1709,43 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg);
+                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg,
+                               (const int*)nullptr);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;
         if (s == 1) {
-            hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                               ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
-                               ix->id_base, D_dev, I_dev, 0, ix->gthr + q0, ix->fix_s, ix->fix_i, ix->fix_lock);
-            CSS_LAUNCH_CHECK();
+            if ((rc = launch_final_select(ix, nq, k, eps_rel, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
+                                          I_dev, pass2 ? ix->thr2 : nullptr, pass2 ? ix->qh2 : nullptr, f2, st)) != CSS_OK)
+                return rc;
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, qpad, ix->xb, ix->dpad,
-                           ix->id_base, D_dev, I_dev, 0, ix->gthr + q0, ix->fix_s, ix->fix_i, ix->fix_lock);
+                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, 0, ix->gthr + q0, ix->fix_s,
+                           ix->fix_i, ix->fix_lock);
         CSS_LAUNCH_CHECK();
     }
+    }
+    if (pass2) {
+        // every launch below reads the flagged count from device memory and returns at once when there is nothing to do
+        ProfScope ps("knn_coarse_pass2", st);
+        const scan_fn f_all = k_scan_coarse8<false, true, false, CZ_CAP2>;   // every row tile against thr2 (the gate also makes tile = ordinal)
+        if ((rc = css::ensure_dynamic_lds((const void*)f_all, lds, ix->device)) != CSS_OK) return rc;
+        const int nqt2 = f2 / CZ_T;
+        {
+            int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
+            hipLaunchKernelGGL(f_all, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh2, ix->thr2, ix->cand_s2, ix->cand_i2,
+                               ix->cand_n2, ix->ntotal, ix->dpad, nqt2, ntiles, (int64_t)1, 1 << 30, pace, ix->cur_mask, xn2, 0,
+                               (const int*)nflag);
+        }
+        hipLaunchKernelGGL(k_rescore_parts<true>, dim3(kRescoreGrid), dim3(256), 0, st, ix->cand_s2, ix->cand_i2, ix->cand_n2,
+                           CZ_CAP2, f2, nflag, flag_list, ix->thr2, l2, qpad, ix->xb, ix->dpad);
+        hipLaunchKernelGGL(k_coarse_select2<CZ_CAP2>, dim3(f2), dim3(256), 0, st, ix->cand_s2, ix->cand_i2, ix->cand_n2, nflag,
+                           flag_list, f2, nflagB, flag_listB, l2, k, ix->id_base, D_dev, I_dev);
+        CSS_LAUNCH_CHECK();
+        // what overflowed the second pass too (tens of thousands of rows inside one band): exact fp32 sweep
+        return launch_fixup(ix, qpad, nq, k, ix->gthr + q0, flag_listB, nflagB, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
+                            sg, st);
     }
     // queries whose candidate buffer or band overflowed (thousands of duplicate rows, a zero query): exact
     // fp32 sweep on the device, two launches that return at once when the flag count is zero
@@ -1830,7 +1907,8 @@ int css_index_free(css_index* ix) {
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock};
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
+                    ix->qh2, ix->thr2, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
@@ -1905,6 +1983,20 @@ int css_index_last_flagged(css_index* ix, int64_t* n) {
     CSS_HIP_TRY(hipDeviceSynchronize());  // diagnostics: whichever stream the search ran on
     int v = 0;
     CSS_HIP_TRY(hipMemcpy(&v, ix->last_nflag, sizeof(int), hipMemcpyDeviceToHost));
+    *n = v;
+    return CSS_OK;
+}
+
+int css_index_last_swept(css_index* ix, int64_t* n) {
+    CSS_REQUIRE(ix && n, "css_index_last_swept: NULL argument");
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);
+    *n = 0;
+    if (ix->last_nswept == nullptr) return CSS_OK;
+    DeviceGuard g(ix->device);
+    CSS_HIP_TRY(hipDeviceSynchronize());
+    int v = 0;
+    CSS_HIP_TRY(hipMemcpy(&v, ix->last_nswept, sizeof(int), hipMemcpyDeviceToHost));
     *n = v;
     return CSS_OK;
 }

@@ -92,9 +92,9 @@ __device__ __forceinline__ unsigned cz_wave_or(unsigned v) {
             asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:%4\n\tds_read_b32 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)" \
                          : "=&v"(fs_), "=&v"(fr_), "=&v"(fq_) : "v"(fa_), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
             const int slot_ = atomicAdd(&cand_n[fq_], 1);                                                              \
-            if (slot_ < CZ_CAP) {                                                                                      \
-                cand_s[(size_t)fq_ * CZ_CAP + slot_] = fs_;                                                            \
-                cand_i[(size_t)fq_ * CZ_CAP + slot_] = fr_;                                                            \
+            if (slot_ < KCAP) {                                                                                      \
+                cand_s[(size_t)fq_ * KCAP + slot_] = fs_;                                                            \
+                cand_i[(size_t)fq_ * KCAP + slot_] = fr_;                                                            \
             }                                                                                                          \
         }                                                                                                              \
         wcount = 0;                                                                                                    \
@@ -120,7 +120,7 @@ _Pragma("unroll")                                                               
                 const int64_t u = u0 + (int64_t)ct_tile * ustep;                                                       \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
-                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + CZ_QOFF(m)) * CZ_CAP + (size_t)u * CZ_T + wc * 64; \
+                    const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + CZ_QOFF(m)) * KCAP + (size_t)u * CZ_T + wc * 64; \
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
@@ -235,13 +235,13 @@ _Pragma("unroll")                                                               
                             /* one returning atomic per lane and query tile reserves the slots of all its hits */      \
                             const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + CZ_QOFF(m));                      \
                             int slot = atomicAdd(&cand_n[qv], __popc(h));                                              \
-                            const size_t qb = (size_t)qv * CZ_CAP;                                                     \
+                            const size_t qb = (size_t)qv * KCAP;                                                     \
 _Pragma("unroll")                                                                                                      \
                             for (int n = 0; n < TN; ++n)                                                               \
 _Pragma("unroll")                                                                                                      \
                                 for (int r = 0; r < NR; ++r) {                                                         \
                                     if ((h >> (n * NR + r)) & 1u) {                                                    \
-                                        if (slot < CZ_CAP) {                                                           \
+                                        if (slot < KCAP) {                                                           \
                                             cand_s[qb + slot] = acc[m][n][r];                                          \
                                             cand_i[qb + slot] = (uint32_t)(row0 + CZ_ROFF(n, r));                      \
                                         }                                                                              \
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
                                                      int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
-                                                     const float* __restrict__ xn2, int dbg_arg) {
+                                                     const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate) {
+    constexpr int KCAP = CZ_CAP;   // candidate slots per query (the shared epilogue macros)
+    (void)gate;
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
     // LDS-DMA loads, bit3 LDS reads without MFMAs, bit4 MFMAs without LDS reads, bit5 half of the LDS reads
@@ -522,15 +524,19 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 constexpr int C8_HT = 16384;
 constexpr int C8_A0 = 0, C8_B0 = 1, C8_B1 = 2, C8_A1 = 3;
 
-template <bool STAGE0, bool MAIN, bool DBG = false>
+// KCAP_T: candidate slots per query (CZ_CAP in the cascade; the second pass over flagged queries has larger buffers).
+// gate (second pass only, else null): number of queries that take part -- the launch is enqueued before that
+// number is known, so blocks whose query tile lies beyond it (all of them when it is 0) return at once.
+template <bool STAGE0, bool MAIN, bool DBG = false, int KCAP_T = CZ_CAP>
 __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __restrict__ xh,
                                                       const unsigned short* __restrict__ qh,
                                                       const float* __restrict__ thr, float* __restrict__ cand_s,
                                                       uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
-                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
+                                                      int64_t ntotal, int K, int nqt_arg, int64_t count, int64_t stride,
                                                       int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
-                                                      const float* __restrict__ xn2, int dbg_arg) {
+                                                      const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate) {
     constexpr int MS = 16, TM = 8, TN = 4, NR = 4;
+    constexpr int KCAP = KCAP_T;
     const int dbg = DBG ? dbg_arg : 0;   // CSS_KNN_DBG (timing experiments): bit0 skips the epilogue
     (void)MAIN;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][C8_HT]
@@ -540,6 +546,13 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
     const int lq = lane & 15, lg = lane >> 4;
 
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    // (second pass: the launch is sized for nqt_arg query tiles, the flagged queries fill the first ceil(*gate / 256))
+    int nqt = nqt_arg;
+    if (gate != nullptr) {
+        const int g = *gate;
+        if (g <= 0) return;
+        nqt = min(nqt_arg, (g + CZ_T - 1) / CZ_T);
+    }
     const int slots = per_x / nqt;
     if (jx >= slots * nqt) return;
     const int qtile = jx % nqt;
@@ -565,7 +578,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
     // tile of ordinal u: STAGE0: u * stride; else (u + u / gm1 + 1) * stride (multiples of the growth factor belong to
     // earlier stages).  u advances by ustep per tile; quotient and remainder by gm1 are carried along, so the loop
     // holds no division.  cur_tile: the tile being computed (what the shared epilogue macro asks for).
-    const int64_t tile0 = (STAGE0 ? u0 : u0 + u0 / gm1 + 1) * stride;
+    // gate != null (second pass): ALL tiles in order, tile = u (the "+ 1" that skips the earlier stages' tiles is undone)
+    const int64_t tbias = gate != nullptr ? -1 : 0;
+    const int64_t tile0 = (STAGE0 ? u0 : u0 + u0 / gm1 + 1) * stride + (STAGE0 ? 0 : tbias);
     int64_t cur_tile = tile0;
     int ucmp = (int)u0, uqc = (int)(u0 / gm1), urc = (int)(u0 % gm1);
 #define CZ_TILE_OF(TI_) (cur_tile)
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
                     ur[KIND_] -= gm1;                                                                         \
                     ++uq[KIND_];                                                                              \
                 }                                                                                             \
-                const int64_t t_ = (STAGE0 ? (int64_t)ucur[KIND_] : (int64_t)ucur[KIND_] + uq[KIND_] + 1) * stride; \
+                const int64_t t_ = STAGE0 ? (int64_t)ucur[KIND_] * stride : ((int64_t)ucur[KIND_] + uq[KIND_] + 1) * stride + tbias; \
                 tbase[KIND_] = (size_t)t_ * CZ_T * (size_t)K * 2u;                                            \
             }                                                                                                 \
         }                                                                                                     \
@@ -754,7 +769,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
                 urc -= gm1;
                 ++uqc;
             }
-            cur_tile = (STAGE0 ? (int64_t)ucmp : (int64_t)ucmp + uqc + 1) * stride;
+            cur_tile = STAGE0 ? (int64_t)ucmp * stride : ((int64_t)ucmp + uqc + 1) * stride + tbias;
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
@@ -913,24 +928,91 @@ __device__ __forceinline__ void cz_bitonic(float* s, uint32_t* id, int P, int ti
     __syncthreads();
 }
 
-// One block per query, between the stages of the cascade (FINAL = false): sort the candidate buffer, take the
-// k-th best coarse score Tc, publish thr = Tc - 2 eps and keep only the entries >= thr.  After the last stage
-// (FINAL = true): rescore the band exactly against the fp32 rows and write the top-k.
+// Exact fp32 scores of candidate rows id[first .. first + R) -> s[first ..]: one wave per row, fixed summation order
+// (lane-strided float4 columns, four fmaf chains, one wave reduction), FOUR rows per wave in flight -- one row at a
+// time made the rescoring of a dense band a chain of dependent HBM latencies (4096 rows: 1.7 ms per query block).
+// Entries whose id is kInvalidRow, or whose current (coarse) score in s[] is below `cmin`, get -inf.
+// IP: x.q; L2: -(||x - q||^2), formed directly as the exact kernels do.  (s / id may be global or LDS arrays.)
+__device__ __forceinline__ void cz_rescore_rows(float* s, const uint32_t* id, int first, int R, const float4* qv,
+                                                const float* __restrict__ xb, int dpad, int l2, int wave, int lane,
+                                                float cmin) {
+    const int nj = dpad >> 2;
+    for (int c0 = first + wave * 4; c0 < first + R; c0 += 16) {
+        const float4* xv[4];
+        bool live[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = c0 + r < first + R ? c0 + r : c0;   // (clamped: the duplicate is not stored)
+            const uint32_t row = id[ci];
+            live[r] = c0 + r < first + R && row != kInvalidRow && s[ci] >= cmin;
+            xv[r] = reinterpret_cast<const float4*>(xb + (size_t)(live[r] ? row : 0u) * dpad);
+        }
+        float a[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[r][e] = 0.f;
+        for (int j = lane; j < nj; j += 64) {
+            const float4 y = qv[j];
+            float4 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = xv[r][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (l2) {
+                    const float dx = x[r].x - y.x, dy = x[r].y - y.y, dz = x[r].z - y.z, dw = x[r].w - y.w;
+                    a[r][0] = fmaf(dx, dx, a[r][0]);
+                    a[r][1] = fmaf(dy, dy, a[r][1]);
+                    a[r][2] = fmaf(dz, dz, a[r][2]);
+                    a[r][3] = fmaf(dw, dw, a[r][3]);
+                } else {
+                    a[r][0] = fmaf(x[r].x, y.x, a[r][0]);
+                    a[r][1] = fmaf(x[r].y, y.y, a[r][1]);
+                    a[r][2] = fmaf(x[r].z, y.z, a[r][2]);
+                    a[r][3] = fmaf(x[r].w, y.w, a[r][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = wave_allsum((a[r][0] + a[r][1]) + (a[r][2] + a[r][3]));
+            if (lane == 0 && c0 + r < first + R) s[c0 + r] = live[r] ? (l2 ? -e : e) : -INFINITY;
+        }
+    }
+}
+
+__device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int l2) {
+    // IP: |c - x.q| <= eps_rel ||q|| max||x||.  L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2):
+    // twice that, plus the fp32 cancellation of the expanded form
+    float eps = eps_rel * sqrtf(qn2) * sqrtf(mx2) + 1e-30f;
+    if (l2) eps = 2.f * eps + 9.5367431640625e-07f * (mx2 + qn2);
+    return eps;
+}
+
+// One block per query.  Between the stages of the cascade (FINAL = false): sort the candidate buffer, take the k-th
+// best coarse score Tc, publish thr = Tc - 2 eps and keep only the entries >= thr.  After the last stage (FINAL =
+// true) the same cut leaves the BAND in the buffer (cand_n = its size), to be rescored exactly by k_rescore_parts
+// and turned into the top-k by k_coarse_final: three launches, because the rescoring of a dense band (hundreds to
+// thousands of rows of one cluster) inside this one-block-per-query kernel was a serial chain of HBM latencies --
+// 1.7 ms per batch on clustered rows in round 2 -- and now spreads over CZ_PARTS blocks per query.
+// A query whose band or buffer overflowed is FLAGGED: flags[q] = its slot in flag_list + 1.  Only the 512 best
+// buffered candidates of such a query are rescored: all that is wanted from them is a lower bound of the exact k-th
+// best score for the second pass, and any subset of rows gives one.
+constexpr int CZ_PARTS = 16;
+constexpr int CZ_FLAGGED_RESCORE = 512;
 template <bool FINAL>
 __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                        int* __restrict__ cand_n, float* __restrict__ thr,
                                                        int* __restrict__ flags, int* __restrict__ nflag,
                                                        int* __restrict__ flag_list, const float* __restrict__ qnorm2,
                                                        const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
-                                                       const float* __restrict__ qpad, const float* __restrict__ xb,
-                                                       int dpad, int64_t id_base, float* __restrict__ D,
-                                                       int64_t* __restrict__ I, int closed_n, int* __restrict__ gthr,
+                                                       int closed_n, int* __restrict__ gthr,
                                                        float* __restrict__ fix_s, uint32_t* __restrict__ fix_i,
                                                        int* __restrict__ fix_lock) {
     __shared__ float s[CZ_CAP];
     __shared__ uint32_t id[CZ_CAP];
     __shared__ int cnt;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x, tid = threadIdx.x;
     const int n_raw = cand_n[q];
     const bool overflow = n_raw > CZ_CAP;
     const int n = min(n_raw, CZ_CAP);
@@ -943,11 +1025,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     if (tid == 0) cnt = 0;
     cz_bitonic(s, id, P, tid);
     const float Tc = n >= k ? s[k - 1] : -INFINITY;
-    // IP: |c - x.q| <= eps_rel ||q|| max||x||.  L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2):
-    // twice that, plus the fp32 cancellation of the expanded form
-    const float mx2 = __int_as_float(*maxn2_bits);
-    float eps = eps_rel * sqrtf(qnorm2[q]) * sqrtf(mx2) + 1e-30f;
-    if (l2) eps = 2.f * eps + 9.5367431640625e-07f * (mx2 + qnorm2[q]);
+    const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(*maxn2_bits), l2);
     const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
     int c = 0;
     for (int i = tid; i < n; i += 256) c += (s[i] >= thr_new && id[i] != kInvalidRow) ? 1 : 0;
@@ -969,58 +1047,168 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
         // last kept rank may continue beyond it
         const bool bad = overflow || flags[q] != 0 || m > CZ_RMAX || (closed_n > 0 && m >= closed_n);
         if (bad) {
-            // flagged: the exact fix-up (k_scan_small<FIX>) recomputes this query; start its global list, threshold
+            // the exact fix-up (k_scan_small<FIX>), should the query get that far, starts its global list, threshold
             // and lock from scratch
             for (int i = tid; i < k; i += 256) {
                 fix_s[(size_t)q * k + i] = -INFINITY;
                 fix_i[(size_t)q * k + i] = kInvalidRow;
             }
-            if (tid == 0) {
+        }
+        const int R = bad ? min(m, CZ_FLAGGED_RESCORE) : m;
+        for (int i = tid; i < R; i += 256) {
+            cand_s[(size_t)q * CZ_CAP + i] = s[i];
+            cand_i[(size_t)q * CZ_CAP + i] = id[i];
+        }
+        if (tid == 0) {
+            cand_n[q] = R;
+            int fl = 0;
+            if (bad) {
                 gthr[q] = f2key(-INFINITY);
                 fix_lock[q] = 0;
-                flag_list[atomicAdd(nflag, 1)] = q;
+                const int slot = atomicAdd(nflag, 1);
+                flag_list[slot] = q;
+                fl = slot + 1;
             }
+            flags[q] = fl;
         }
-        const int R = min(m, CZ_RMAX);
-        __syncthreads();
-        // exact fp32 scores of the band rows: one wave per row, fixed summation order
+    }
+}
+
+// Exact scores for candidate buffers, CZ_PARTS work items per buffer, grid-stride over the items.
+//   PASS2 = false: buffer of query q = slot (cap CZ_CAP, cand_n[q] band rows left by k_coarse_select<true>);
+//   PASS2 = true:  buffer of slot b < min(*nflag, f2max) belongs to query flag_list[b] (cap entries per slot);
+//                  a slot that overflowed is left to k_coarse_select2.
+template <bool PASS2>
+__global__ __launch_bounds__(256) void k_rescore_parts(float* __restrict__ cand_s, const uint32_t* __restrict__ cand_i,
+                                                       const int* __restrict__ cand_n, int cap, int nslots_arg,
+                                                       const int* __restrict__ nflag, const int* __restrict__ flag_list,
+                                                       const float* __restrict__ thr2, int l2,
+                                                       const float* __restrict__ qpad, const float* __restrict__ xb, int dpad) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nslots = PASS2 ? min(*nflag, nslots_arg) : nslots_arg;
+    for (int item = blockIdx.x; item < nslots * CZ_PARTS; item += gridDim.x) {
+        const int slot = item / CZ_PARTS, part = item % CZ_PARTS;
+        const int n = cand_n[slot];
+        if (n > cap) continue;
+        const int per = (((n + CZ_PARTS - 1) / CZ_PARTS) + 15) & ~15;
+        const int lo = part * per, hi = min(n, lo + per);
+        if (lo >= hi) continue;
+        const int q = PASS2 ? flag_list[slot] : slot;
         const float4* qv = reinterpret_cast<const float4*>(qpad + (size_t)q * dpad);
-        for (int cidx = wave; cidx < R; cidx += 4) {
-            const float4* xv = reinterpret_cast<const float4*>(xb + (size_t)id[cidx] * dpad);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            if (l2) {  // -(squared distance), formed directly as the exact kernels do
-                for (int j = lane; j < (dpad >> 2); j += 64) {
-                    const float4 x = xv[j], y = qv[j];
-                    const float dx = x.x - y.x, dy = x.y - y.y, dz = x.z - y.z, dw = x.w - y.w;
-                    a0 = fmaf(dx, dx, a0);
-                    a1 = fmaf(dy, dy, a1);
-                    a2 = fmaf(dz, dz, a2);
-                    a3 = fmaf(dw, dw, a3);
-                }
-            } else {
-                for (int j = lane; j < (dpad >> 2); j += 64) {
-                    const float4 x = xv[j], y = qv[j];
-                    a0 = fmaf(x.x, y.x, a0);
-                    a1 = fmaf(x.y, y.y, a1);
-                    a2 = fmaf(x.z, y.z, a2);
-                    a3 = fmaf(x.w, y.w, a3);
-                }
-            }
-            const float e = wave_allsum((a0 + a1) + (a2 + a3));
-            if (lane == 0) s[cidx] = l2 ? -e : e;
+        cz_rescore_rows(cand_s + (size_t)slot * cap, cand_i + (size_t)slot * cap, lo, hi - lo, qv, xb, dpad, l2, wave, lane,
+                        PASS2 ? thr2[slot] : -INFINITY);
+    }
+}
+
+// One block per query: the band, now with exact scores, is sorted by (score desc, id asc) and its k best rows are
+// the answer.  thr2 / qh2 / f2max (cascade only, else null / 0): a flagged query that holds one of the first f2max
+// slots of flag_list also leaves what the SECOND coarse pass needs (launch_scan_coarse): its bf16 row and the
+// threshold s_k - eps, s_k = exact k-th best score among the rows rescored -- every row of the exact top-k has an
+// exact score >= s_k, hence a coarse score >= s_k - eps (one eps, from exact scores; the cascade's own thresholds
+// are k-th best COARSE scores minus two eps).
+__global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_i,
+                                                      const int* __restrict__ cand_n, const int* __restrict__ flags,
+                                                      const float* __restrict__ qnorm2, const int* __restrict__ maxn2_bits,
+                                                      float eps_rel, int l2, int k, const float* __restrict__ qpad, int dpad,
+                                                      int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
+                                                      float* __restrict__ thr2, unsigned short* __restrict__ qh2, int f2max) {
+    __shared__ float s[CZ_CAP];
+    __shared__ uint32_t id[CZ_CAP];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int R = min(cand_n[q], CZ_CAP);
+    int P = 2;
+    while (P < R) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        s[i] = i < R ? cand_s[(size_t)q * CZ_CAP + i] : -INFINITY;
+        id[i] = i < R ? cand_i[(size_t)q * CZ_CAP + i] : kInvalidRow;
+        if (s[i] == -INFINITY) id[i] = kInvalidRow;   // (dropped by the rescoring)
+    }
+    cz_bitonic(s, id, P, tid);
+    for (int i = tid; i < k; i += 256) {
+        const bool ok = i < R && id[i] != kInvalidRow;
+        D[(size_t)q * k + i] = l2 ? (ok ? -s[i] : FLT_MAX) : (ok ? s[i] : -FLT_MAX);
+        I[(size_t)q * k + i] = ok ? id_base + (int64_t)id[i] : (int64_t)-1;
+    }
+    const int fslot = flags[q] - 1;
+    if (fslot >= 0 && thr2 != nullptr && fslot < f2max) {
+        // second coarse pass: coarse scores are x.q (IP) or 2 x.q - ||x||^2 = -(||x - q||^2) + ||q||^2 (L2)
+        if (tid == 0) {
+            const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(*maxn2_bits), l2);
+            thr2[fslot] = (R >= k && id[k - 1] != kInvalidRow) ? s[k - 1] + (l2 ? qnorm2[q] : 0.f) - eps : -INFINITY;
         }
-        int P2 = 2;
-        while (P2 < R) P2 <<= 1;
+        for (int i = tid; i < dpad; i += 256)
+            qh2[(size_t)fslot * dpad + i] = __builtin_bit_cast(unsigned short, (__bf16)qpad[(size_t)q * dpad + i]);
+    }
+}
+
+// Second pass over flagged queries: slot b (< min(*nflag, f2max)) holds query flag_list[b]; its candidates -- every
+// row whose coarse score reached thr2[b] -- carry exact scores (k_rescore_parts<true>) and are folded into a running
+// top-k, CZ_CAP - 128 at a time; from the second chunk on only entries that reach the current k-th best are sorted.
+// A slot whose buffer overflowed again, and every flagged query beyond the f2max slots, goes on to list B, which the
+// exact fp32 sweep (launch_fixup) works off.
+template <int CAP2>
+__global__ __launch_bounds__(256) void k_coarse_select2(const float* __restrict__ cand_s, const uint32_t* __restrict__ cand_i,
+                                                        const int* __restrict__ cand_n, const int* __restrict__ nflag,
+                                                        const int* __restrict__ flag_list, int f2max,
+                                                        int* __restrict__ nflagB, int* __restrict__ flag_listB, int l2, int k,
+                                                        int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I) {
+    __shared__ float s[CZ_CAP];
+    __shared__ uint32_t id[CZ_CAP];
+    __shared__ int cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nf = *nflag;
+    if (b == 0)   // flagged queries without a slot
+        for (int i = f2max + tid; i < nf; i += 256) flag_listB[atomicAdd(nflagB, 1)] = flag_list[i];
+    if (b >= min(nf, f2max)) return;
+    const int q = flag_list[b];
+    const int n = cand_n[b];
+    if (n > CAP2) {
+        if (tid == 0) flag_listB[atomicAdd(nflagB, 1)] = q;
+        return;
+    }
+    constexpr int CH = CZ_CAP - 128;   // k <= 128 entries carried in front
+    for (int i = tid; i < k; i += 256) {
+        s[i] = -INFINITY;
+        id[i] = kInvalidRow;
+    }
+    float tk = -INFINITY;   // k-th best exact score so far
+    for (int base = 0; base < n; base += CH) {
+        const int cn = min(CH, n - base);
+        if (tid == 0) cnt = k;
         __syncthreads();
-        for (int i = R + tid; i < P2; i += 256) {
+        for (int i = tid; i < cn; i += 256) {
+            const float e = cand_s[(size_t)b * CAP2 + base + i];
+            if (e != -INFINITY && e >= tk) {
+                const int pos = atomicAdd(&cnt, 1);
+                s[pos] = e;
+                id[pos] = cand_i[(size_t)b * CAP2 + base + i];
+            }
+        }
+        __syncthreads();
+        const int tot = cnt;
+        int P = 2;
+        while (P < tot) P <<= 1;
+        for (int i = tot + tid; i < P; i += 256) {
             s[i] = -INFINITY;
             id[i] = kInvalidRow;
         }
-        cz_bitonic(s, id, P2, tid);
-        for (int i = tid; i < k; i += 256) {
-            const bool ok = i < R && id[i] != kInvalidRow;
-            D[(size_t)q * k + i] = l2 ? (ok ? -s[i] : FLT_MAX) : (ok ? s[i] : -FLT_MAX);
-            I[(size_t)q * k + i] = ok ? id_base + (int64_t)id[i] : (int64_t)-1;
-        }
+        cz_bitonic(s, id, P, tid);   // (starts and ends with a block barrier)
+        tk = s[k - 1];
+        __syncthreads();
+    }
+    for (int i = tid; i < k; i += 256) {
+        const bool ok = id[i] != kInvalidRow;
+        D[(size_t)q * k + i] = l2 ? (ok ? -s[i] : FLT_MAX) : (ok ? s[i] : -FLT_MAX);
+        I[(size_t)q * k + i] = ok ? id_base + (int64_t)id[i] : (int64_t)-1;
+    }
+}
+
+// counters / thresholds of the second pass
+__global__ void k_coarse_init2(int* __restrict__ cand_n2, float* __restrict__ thr2, int* __restrict__ nflagB, int f2max) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *nflagB = 0;
+    if (i < f2max) {
+        cand_n2[i] = 0;
+        thr2[i] = INFINITY;   // slots no flagged query claims take part in the scan without ever appending
     }
 }

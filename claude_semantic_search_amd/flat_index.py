@@ -98,6 +98,13 @@ class IndexFlat:
             return
         nat.check(nat.lib().css_index_add(self._handle(), a.ctypes.data, a.shape[0], 1 if normalize else 0))
 
+    def add_dev(self, x_ptr: int, n: int, normalize: bool = False, stream: int = 0) -> None:
+        """Device-pointer twin of ``add``: ``x_ptr`` = device address of ``[n, d]`` fp32 rows (``tensor.data_ptr()``),
+        enqueued on ``stream``; later searches are ordered behind it by the library."""
+        if n:
+            nat.check(nat.lib().css_index_add_dev(self._handle(), ctypes.c_void_p(x_ptr), int(n), 1 if normalize else 0,
+                                                  ctypes.c_void_p(stream)))
+
     def add_synthetic(self, n: int, seed: int, first_row: int = 0, normalize: bool = True, stream: int = 0) -> None:
         nat.check(nat.lib().css_index_add_synthetic(self._handle(), int(n), ctypes.c_uint64(seed), int(first_row),
                                                     1 if normalize else 0, ctypes.c_void_p(stream)))
@@ -144,9 +151,16 @@ class IndexFlat:
         nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))
 
     def last_flagged(self) -> int:
-        """Diagnostics: queries of the last candidate-path search that were re-run by the exact fix-up."""
+        """Diagnostics: queries of the last candidate-path search whose candidate band or buffer overflowed."""
         n = ctypes.c_int64(0)
         nat.check(nat.lib().css_index_last_flagged(self._handle(), ctypes.byref(n)))
+        return int(n.value)
+
+    def last_swept(self) -> int:
+        """Diagnostics: flagged queries of the last candidate-path search that the second coarse pass could not settle
+        and that the exact fp32 sweep re-ran."""
+        n = ctypes.c_int64(0)
+        nat.check(nat.lib().css_index_last_swept(self._handle(), ctypes.byref(n)))
         return int(n.value)
 
     def set_shadow(self, policy: Optional[bool]) -> None:

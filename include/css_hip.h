@@ -82,8 +82,11 @@ int css_index_dim(const css_index* ix, int* dim);
 int css_index_metric(const css_index* ix, int* metric);
 int css_index_device(const css_index* ix, int* device);
 /* Diagnostics: how many queries of the LAST candidate-path search (its last chunk of up to 4096 queries) overflowed
- * their candidate buffer or band and were re-run by the exact fix-up.  Waits for the device. */
+ * their candidate buffer or band (and were settled by the second coarse pass or the exact sweep).  Waits for the device. */
 int css_index_last_flagged(css_index* ix, int64_t* n);
+/* ... and how many of those the second coarse pass could not settle either (candidate buffers of 32768 rows
+ * overflowed, or more than 1024 flagged queries in a chunk): these were re-run by the exact fp32 sweep. */
+int css_index_last_swept(css_index* ix, int64_t* n);
 /* bf16 shadow rows (the operand of the candidate scans; +50 % HBM next to the fp32 rows): -1 = keep them
  * while fp32 + bf16 rows fit in 80 % of the HBM (default), 0 = never, 1 = always.  Only on an empty index.
  * Results do not depend on it: without shadow rows batches form their candidate scores from the fp32 rows. */

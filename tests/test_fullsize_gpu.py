@@ -215,3 +215,59 @@ def test_config0_ten_thousand_chunks_encode_index_search_chain():
             assert_topk_matches(Dh, Ih, Dr, Ir, D64, f"config0 k={k} [{mode}]", D64_next=D641[:, k])
             assert (Ih[:, 0] == np.arange(0, n, 100)).all() and np.abs(Dh[:, 0] - 1).max() < 1e-5
     ix.close()
+
+
+def test_10m_clustered_rows_second_pass_matches_the_cpu_oracle():
+    """dense candidate bands at the benchmark's size.  10 M rows in 2 000 tight clusters = 5 000
+    near-identical rows per cluster, more than the cascade's 4 096-slot candidate buffers hold: every query near a
+    cluster centre is flagged and settled by the SECOND coarse pass (threshold from the exactly rescored buffered
+    candidates, 32 768-slot buffers) -- none may fall through to the exact fp32 sweep, which round 2 used for all
+    of them (8 queries per 30 GB pass).  Rows are generated on the device (synth.rows_torch, bit-identical to the
+    host generator: spot-checked), exported 1 M at a time, and the CPU oracle answers per chunk + merge."""
+    import torch
+
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+    from knn_checks import assert_topk_matches
+    from oracle import knn_oracle as ko
+
+    n, nc, chunk = 10_000_000, 2000, 250_000
+    dev = torch.device("cuda:0")
+    cent = synth.rows(nc, D, 71)
+    cent_d = torch.from_numpy(cent).to(dev)
+    ix = IndexFlatIP(D)
+    ix.reserve(n)
+    for c0 in range(0, n, chunk):
+        ids = torch.arange(c0, c0 + chunk, device=dev) % nc
+        rows = cent_d[ids] + 0.05 * synth.rows_torch(chunk, D, 72 + c0 // chunk, device=dev)
+        ix.add_dev(rows.data_ptr(), chunk, normalize=True)
+        torch.cuda.synchronize()
+    # the device generator is the host generator: three rows of the last chunk, regenerated with numpy (bit for bit
+    # before the ingest kernel normalises them; its sum of squares has another summation order than the oracle's)
+    c0 = n - chunk
+    host = cent[(np.arange(c0 + 7, c0 + 10) % nc)] + 0.05 * synth.rows(3, D, 72 + c0 // chunk, first_row=7)
+    assert np.array_equal(rows[7:10].cpu().numpy(), host)
+    assert np.allclose(ix.reconstruct_n(c0 + 7, 3), ko.normalize_rows(host), rtol=0, atol=2e-8)
+    del cent_d, rows
+    q = np.concatenate([cent[5:21] + 0.02 * synth.rows(16, D, 90), synth.rows(8, D, 91)])
+    qn = ko.normalize_rows(q)
+    nq = q.shape[0]
+    parts_d, parts_i = [], []
+    for r0 in range(0, n, 1_000_000):
+        xb = ix.reconstruct_n(r0, 1_000_000)
+        d_, i_ = ko.search_blas(xb, qn, K + 1)
+        parts_d.append(d_)
+        parts_i.append(np.where(i_ >= 0, i_ + r0, -1))
+    Dr, Ir = ko.merge_topk(np.stack(parts_d), np.stack(parts_i), 0)
+    Dr, Ir = Dr[:, :K + 1], Ir[:, :K + 1]
+    D64 = np.stack([np.stack([ix.reconstruct(int(i)) for i in Ir[r]]).astype(np.float64) @ qn[r].astype(np.float64)
+                    for r in range(nq)])
+    for mode in ("coarse", "auto"):
+        ix.set_search_mode(mode)
+        Da, Ia = ix.search(q, K, normalize=True)
+        assert_topk_matches(Da, Ia, Dr[:, :K], Ir[:, :K], D64[:, :K], f"10M clustered [{mode}]", D64_next=D64[:, K])
+        assert ix.last_flagged() >= 16 and ix.last_swept() == 0, (ix.last_flagged(), ix.last_swept())
+    # the single-query path (bf16 sweep cascade; a flagged query there is re-run by the exact sweep)
+    Da, Ia = ix.search(q[:1], K, normalize=True)
+    assert_topk_matches(Da, Ia, Dr[:1, :K], Ir[:1, :K], D64[:1, :K], "10M clustered nq=1", D64_next=D64[:1, K])
+    ix.close()

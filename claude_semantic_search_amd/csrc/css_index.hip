@@ -1511,7 +1511,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
         CSS_HIP_TRY(hipMemsetAsync(qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, gthr, nq_pad, host_f2key(-INFINITY));
     hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags, nflag,
-                       nq, nq_pad, 0);
+                       nq, nq_pad, 0, (int*)nullptr, 0, (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
     const int64_t ne = (int64_t)nq_pad * ix->dpad;
     hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qsplit,
                        (int64_t)nq_pad, ix->dpad);
@@ -1648,6 +1648,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         for (int64_t s = s0 / g; s >= 1; s /= g) sched.push_back({s, g});
     }
     const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
+    constexpr int kPaceGroups = 512, kPaceStages = 20;
+    const bool use_pace = !sweep && env.pacing;
+    if (use_pace && (rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
 
     {
         if (!sweep) {
@@ -1656,10 +1659,11 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
                                (int64_t)nq, (int64_t)nq_pad, ix->dpad);
             CSS_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
-                           nflag, nq, nq_pad, (int)(n0 * CZ_T));
-        if (pass2)
-            hipLaunchKernelGGL(k_coarse_init2, dim3((f2 + 255) / 256), dim3(256), 0, st, ix->cand_n2, ix->thr2, nflagB, f2);
+        const int npace = use_pace ? kPaceGroups * kPaceStages : 0;
+        const int ninit = std::max(std::max(nq_pad, npace), f2);
+        hipLaunchKernelGGL(k_coarse_init, dim3((ninit + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
+                           nflag, nq, nq_pad, (int)(n0 * CZ_T), use_pace ? ix->cpace : (int*)nullptr, npace,
+                           pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2);
         CSS_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
@@ -1684,11 +1688,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             if ((rc = css::ensure_dynamic_lds((const void*)f, lds, ix->device)) != CSS_OK) return rc;
     const int grid = coarse_grid(ix);
     CSS_REQUIRE(sweep || (grid / 8) / nqt >= 1, "css_index_search: %d query tiles do not fit a grid of %d blocks", nqt, grid);
-    constexpr int kPaceGroups = 512, kPaceStages = 20;
-    if (!sweep && env.pacing) {
-        if ((rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
-        CSS_HIP_TRY(hipMemsetAsync(ix->cpace, 0, sizeof(int) * kPaceGroups * kPaceStages, st));
-    }
+
     int stage_idx = 0;
     {
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);

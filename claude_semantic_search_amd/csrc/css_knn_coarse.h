@@ -50,10 +50,22 @@ __global__ void k_rows_to_bf16(const float* __restrict__ in, unsigned short* __r
     out[i] = __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 
-// thr = -inf (real queries) / +inf (padding), counters and flags cleared
-__global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, int nq, int nq_pad, int n0rows) {
+// thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
+// the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
+// flagged query claims take part in that scan with thr2 = +inf, i.e. without ever appending
+__global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, int nq, int nq_pad, int n0rows,
+                              int* __restrict__ pace, int npace, int* __restrict__ cand_n2, float* __restrict__ thr2,
+                              int* __restrict__ nflagB, int f2max) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *nflag = 0;
+    if (i == 0) {
+        *nflag = 0;
+        if (nflagB) *nflagB = 0;
+    }
+    if (i < npace) pace[i] = 0;
+    if (i < f2max) {
+        cand_n2[i] = 0;
+        thr2[i] = INFINITY;
+    }
     if (i >= nq_pad) return;
     thr[i] = i < nq ? -INFINITY : INFINITY;
     cand_n[i] = i < nq ? n0rows : 0;   // stage 0 writes its rows to fixed slots
@@ -1203,12 +1215,3 @@ __global__ __launch_bounds__(256) void k_coarse_select2(const float* __restrict_
     }
 }
 
-// counters / thresholds of the second pass
-__global__ void k_coarse_init2(int* __restrict__ cand_n2, float* __restrict__ thr2, int* __restrict__ nflagB, int f2max) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *nflagB = 0;
-    if (i < f2max) {
-        cand_n2[i] = 0;
-        thr2[i] = INFINITY;   // slots no flagged query claims take part in the scan without ever appending
-    }
-}

@@ -827,6 +827,10 @@ def _main(argv, platform_factory):
             extra["clustered_1M"] = {"error": repr(ex_)}
         if args.rows >= 10_000_000:
             index.close()   # (46 GB back before three more 10 M-row indexes are built, one at a time)
+            try:   # an index without bf16 shadow rows (what a > 38 M-row shard gets): ranges of on-the-fly bf16 rows vs the split-operand scan
+                extra["no_shadow_10M"] = bench_no_shadow(args, dev, stream, log)
+            except Exception as ex_:
+                extra["no_shadow_10M"] = {"error": repr(ex_)}
             for nc_ in (20000, 2000):   # 500 and 5000 rows per cluster: a band fits the cascade's buffers / only the second pass's
                 try:
                     extra[f"clustered_10M_{nc_}_clusters"] = bench_clustered(args, dev, stream, log, n=10_000_000, nc=nc_,
@@ -898,6 +902,57 @@ def _main(argv, platform_factory):
 def index_id_base(sh):
     """Global id of this shard's local row 0 (one segment: the synthetic bench index)."""
     return sh.segments[0][1] - sh.segments[0][0] if sh.segments else 0
+
+
+def bench_no_shadow(args, dev, stream, log, n=10_000_000):
+    """The benchmark's index (seed 4) WITHOUT bf16 shadow rows, the state of a shard beyond ~38 M rows per GPU: a
+    batch rounds the rows to bf16 range by range into scratch memory and runs the cascade of shadowed indexes per
+    range ("ranges", the default); "split" = the split-operand candidate scan it replaced (CSS_SEARCH_SPLIT)."""
+    import numpy as np
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(args.dim, device=dev.index or 0)
+    ix.set_shadow(False)
+    ix.reserve(n)
+    ix.add_synthetic(n, seed=4, first_row=0, normalize=True, stream=stream)
+    qd = torch.from_numpy(synth.rows(args.nq, args.dim, 5)).to(dev)
+    Dd = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+    Id = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
+    out = {"rows": n, "nq": args.nq, "k": args.k}
+    ref = None
+    for mode in ("auto", "split"):
+        ix.set_search_mode(mode)
+        for _ in range(2):
+            ix.search_dev(qd.data_ptr(), args.nq, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+        torch.cuda.synchronize()
+        nat.prof_reset()
+        nat.prof_enable(True)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ix.search_dev(qd.data_ptr(), args.nq, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        nat.prof_enable(False)
+        cms, cn = nat.prof_read("knn_rows_to_bf16")
+        nat.prof_reset()
+        rec = {"ms_per_batch": dt * 1e3, "queries_per_s": args.nq / dt}
+        if cn:
+            rec["rows_to_bf16_ms"] = cms / reps
+        out["ranges" if mode == "auto" else "split"] = rec
+        if ref is None:
+            ref = (Dd.clone(), Id.clone())
+        else:   # both paths return exact fp32 scores (ids may swap inside fp32 near-ties: another summation order in the fix-up)
+            out["id_mismatch_fraction_between_paths"] = float((ref[1] != Id).float().mean())
+            out["max_score_difference_between_paths"] = float((ref[0] - Dd).abs().max())
+            assert out["max_score_difference_between_paths"] < 1e-4 and out["id_mismatch_fraction_between_paths"] < 1e-2
+    ix.close()
+    log(f"no shadow rows, {n} rows: ranges {out['ranges']['ms_per_batch']:.1f} ms, split-operand scan {out['split']['ms_per_batch']:.1f} ms per batch")
+    return out
 
 
 def bench_clustered(args, dev, stream, log, n=1_000_000, nc=2000, with_uniform=True):

@@ -29,6 +29,7 @@
 #include "../../include/css_synth.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <string>
 #include <cfloat>
@@ -43,6 +44,9 @@ using namespace css;
 struct css_index {
     int dim = 0, dpad = 0, metric = 0, device = 0;
     int64_t ntotal = 0, cap = 0, id_base = 0;
+    // what css_index_ntotal reports: searches of shadow-less indexes temporarily narrow xb / xnorm2 / ntotal / id_base
+    // to a row range (RowView, under ws_mu), and a concurrent reader must not see that
+    std::atomic<int64_t> ntotal_pub{0};
     float* xb = nullptr;
     float* xnorm2 = nullptr;
     unsigned short* xh = nullptr;  // bf16 shadow rows [cap][dpad] for the coarse scan (nullptr: not kept)
@@ -81,6 +85,10 @@ struct css_index {
     float* cand_s2 = nullptr; size_t cand_s2_cap = 0;
     uint32_t* cand_i2 = nullptr; size_t cand_i2_cap = 0;
     int* flagB = nullptr;     size_t flagB_cap = 0;      // [nq_pad] list | [1] count: queries left to the exact sweep
+    // shadow-less indexes: bf16 rows of one row range at a time + the per-range top-k lists (search_noshadow_ranges)
+    unsigned short* xh_tmp = nullptr; size_t xh_tmp_cap = 0;
+    int64_t range_rows = 0;   // css_index_set_range_rows: rows per range (0: from the free HBM, at most 2^24)
+    float* rng_d = nullptr;   int64_t* rng_i = nullptr;  size_t rng_cap = 0;
     const int* last_nswept = nullptr;                    // device counter behind css_index_last_swept
     // rows written by css_index_add_dev / _add_synthetic on the CALLER's stream: searches, reallocation and
     // export wait for this event before touching rows, norms or maxn2
@@ -1252,6 +1260,7 @@ struct KnnEnv {
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
     int loop8 = 1;        // CSS_KNN_LOOP=old: the round-1 main loop (k_scan_coarse) instead of k_scan_coarse8 (A/B runs)
     int pass2 = 1;        // CSS_KNN_PASS2=0: flagged queries go straight to the exact fp32 sweep (A/B runs)
+    int noshadow_ranges = 1;   // CSS_KNN_NOSHADOW=split: shadow-less batches through the split-operand scan (A/B runs)
 };
 const KnnEnv& knn_env() {
     static const KnnEnv env = [] {
@@ -1267,6 +1276,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
         if (const char* m = getenv("CSS_KNN_LOOP")) e.loop8 = std::string(m) == "old" ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_PASS2")) e.pass2 = m[0] == '0' ? 0 : 1;
+        if (const char* m = getenv("CSS_KNN_NOSHADOW")) e.noshadow_ranges = std::string(m) == "split" ? 0 : 1;
         return e;
     }();
     return env;
@@ -1753,6 +1763,141 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
                         sg, st);
 }
 
+// sweep geometry of the small-batch kernel (also the exact fix-up of the candidate paths) for the rows in view
+int make_sweep_geom(const css_index* ix, int k, SweepGeom* sg) {
+    sg->nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 8));
+    CSS_REQUIRE(sg->nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
+    // enough blocks to fill the chip (8 per CU) but at least ~64 row groups of work each
+    const int64_t ngroups = (ix->ntotal + 3) / 4;
+    int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ix->num_cus * 8, (ngroups + 63) / 64));
+    sg->gpb = (ngroups + G - 1) / G;
+    sg->G = (int)((ngroups + sg->gpb - 1) / sg->gpb);
+    return CSS_OK;
+}
+
+// RAII: the index narrowed to rows [row0, row0 + n) with `xh` as their bf16 shadow rows -- every launcher below reads
+// rows, norms, count, id base and the allow-bitmap through the css_index fields, so a row range is searched exactly
+// like an index of its own.  Caller holds ws_mu (export and css_index_ntotal do not look at these fields unguarded).
+struct RowView {
+    css_index* ix;
+    float* xb;
+    float* xnorm2;
+    unsigned short* xh;
+    int64_t ntotal, id_base;
+    const uint32_t* mask;
+    RowView(css_index* i, int64_t row0, int64_t n, unsigned short* xh_rows)
+        : ix(i), xb(i->xb), xnorm2(i->xnorm2), xh(i->xh), ntotal(i->ntotal), id_base(i->id_base), mask(i->cur_mask) {
+        ix->xb = xb + (size_t)row0 * ix->dpad;
+        ix->xnorm2 = xnorm2 + row0;
+        ix->xh = xh_rows;
+        ix->ntotal = n;
+        ix->id_base = id_base + row0;
+        if (mask) ix->cur_mask = mask + row0 / 32;   // (row0 is a multiple of 256)
+    }
+    ~RowView() {
+        ix->xb = xb;
+        ix->xnorm2 = xnorm2;
+        ix->xh = xh;
+        ix->ntotal = ntotal;
+        ix->id_base = id_base;
+        ix->cur_mask = mask;
+    }
+};
+
+int merge_parts(const float* Dp, const int64_t* Ip, int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
+                int metric, float* D, int64_t* I, int device, void* stream, const char* who) {
+    CSS_REQUIRE(Dp && Ip && D && I, "%s: NULL buffer", who);
+    CSS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= CSS_MAX_K, "%s: bad sizes", who);
+    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "%s: unknown metric", who);
+    int rc = css::check_device(device);
+    if (rc != CSS_OK) return rc;
+    if (nq == 0) return CSS_OK;
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("knn_merge_parts", st);
+    if (metric == CSS_METRIC_IP)
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
+                           stride_i, nq, k, D, I);
+    else
+        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
+                           stride_i, nq, k, D, I);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+// Batches on an index WITHOUT bf16 shadow rows (more than ~38 M rows of 768 floats on one 288 GB GPU, or
+// css_index_set_shadow(ix, 0)): the rows are rounded to bf16 one range at a time into a scratch buffer sized from
+// the free HBM, every range is searched by the SAME cascade as a shadowed index (same error band: the scratch
+// rows are exactly the shadow rows it would have had), and the per-range top-k lists are merged.  Per 10 M rows:
+// 46 GB of conversion traffic + the 13.6 ms cascade, against 45-48 ms for the split-operand scan it replaces (three
+// MFMA products per score, 4.4 x its algorithmic bytes), and the cost of the conversion is shared by up to 4096
+// queries.  Returns CSS_ERR_STATE without touching the outputs when no scratch of at least 2^20 rows can be had.
+int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
+    int rc;
+    const int64_t ntotal = ix->ntotal;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CSS_ERR_STATE;
+    const size_t row_b = (size_t)ix->dpad * 2;
+    int64_t rows_fit = (int64_t)((free_b + ix->xh_tmp_cap * 2) / 2 / row_b);          // half of what is free (incl. our own scratch)
+    rows_fit = std::min<int64_t>(rows_fit, 16ll << 20) / CZ_T * CZ_T;
+    int64_t S = std::min<int64_t>((ntotal + CZ_T - 1) / CZ_T * CZ_T, rows_fit);
+    if (S < std::min<int64_t>(ntotal, 1ll << 20)) return CSS_ERR_STATE;
+    if (ix->range_rows > 0) S = std::min<int64_t>(S, (ix->range_rows + CZ_T - 1) / CZ_T * CZ_T);
+    if ((size_t)S * ix->dpad > ix->xh_tmp_cap) {   // (exact size: grow() would double a multi-GB buffer)
+        if (ix->xh_tmp) CSS_HIP_TRY(hipFree(ix->xh_tmp));
+        ix->xh_tmp = nullptr;
+        ix->xh_tmp_cap = 0;
+        if (hipMalloc((void**)&ix->xh_tmp, (size_t)S * row_b) != hipSuccess) {
+            (void)hipGetLastError();
+            return CSS_ERR_STATE;
+        }
+        ix->xh_tmp_cap = (size_t)S * ix->dpad;
+    }
+    const int nranges = (int)((ntotal + S - 1) / S);
+    float* Dp = D_dev;
+    int64_t* Ip = I_dev;
+    if (nranges > 1) {
+        const size_t need = (size_t)nranges * nq * k;
+        if (need > ix->rng_cap) {
+            if (ix->rng_d) CSS_HIP_TRY(hipFree(ix->rng_d));
+            if (ix->rng_i) CSS_HIP_TRY(hipFree(ix->rng_i));
+            ix->rng_d = nullptr;
+            ix->rng_i = nullptr;
+            ix->rng_cap = 0;
+            CSS_HIP_TRY(hipMalloc((void**)&ix->rng_d, need * sizeof(float)));
+            CSS_HIP_TRY(hipMalloc((void**)&ix->rng_i, need * sizeof(int64_t)));
+            ix->rng_cap = need;
+        }
+    }
+    ProfScope all("knn_noshadow_ranges", st);
+    for (int r = 0; r < nranges; ++r) {
+        const int64_t row0 = (int64_t)r * S, n = std::min<int64_t>(S, ntotal - row0);
+        {
+            ProfScope ps("knn_rows_to_bf16", st);
+            const int64_t n8 = n * ix->dpad / 8;   // (dpad is a multiple of 64)
+            const unsigned blocks = (unsigned)std::min<int64_t>((n8 + 255) / 256, (int64_t)ix->num_cus * 64);
+            hipLaunchKernelGGL(k_rows_to_bf16_x8, dim3(blocks), dim3(256), 0, st, ix->xb + (size_t)row0 * ix->dpad, ix->xh_tmp, n8);
+            CSS_LAUNCH_CHECK();
+        }
+        if (nranges > 1) {
+            Dp = ix->rng_d + (size_t)r * nq * k;
+            Ip = ix->rng_i + (size_t)r * nq * k;
+        }
+        RowView view(ix, row0, n, ix->xh_tmp);
+        SweepGeom sg;
+        if ((rc = make_sweep_geom(ix, k, &sg)) != CSS_OK) return rc;
+        const int chunk = coarse_max_chunk(ix);
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+            const int nqc = (int)std::min<int64_t>(chunk, nq - q0);
+            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, Dp, Ip, st, sg, false)) != CSS_OK) return rc;
+        }
+    }
+    if (nranges > 1)
+        return merge_parts(ix->rng_d, ix->rng_i, nranges, nq * k, nq * k, nq, k, ix->metric, D_dev, I_dev, ix->device, st,
+                           "css_index_search");
+    return CSS_OK;
+}
+
 // q_dev: raw [nq, dim] device queries.  Caller holds ws_mu and a shared lock on mu.
 int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
                        int64_t* I_dev, hipStream_t st);
@@ -1798,15 +1943,8 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
         CSS_LAUNCH_CHECK();
         return CSS_OK;
     }
-    // sweep geometry of the small-batch kernel (also the exact fix-up of the candidate paths)
     SweepGeom sg;
-    sg.nq_sweep = (int)std::min<int64_t>(16, (64 * 1024) / ((int64_t)ix->dpad * 4 + (int64_t)k * 8 + 8));
-    CSS_REQUIRE(sg.nq_sweep >= 1, "css_index_search: dim=%d too large for the scan kernel", ix->dim);
-    // enough blocks to fill the chip (8 per CU) but at least ~64 row groups of work each
-    const int64_t ngroups = (ix->ntotal + 3) / 4;
-    int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ix->num_cus * 8, (ngroups + 63) / 64));
-    sg.gpb = (ngroups + G - 1) / G;
-    sg.G = (int)((ngroups + sg.gpb - 1) / sg.gpb);
+    if ((rc = make_sweep_geom(ix, k, &sg)) != CSS_OK) return rc;
 
     const int mode = ix->search_mode;
     const bool batch_ok = nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0;  // the MFMA scan kernels apply
@@ -1814,6 +1952,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     // 10 k rows, crossover ~1.2 M; 8 queries crossover ~0.4 M; 32+ queries always ahead) the exact fp32 kernels
     // answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
     const bool coarse_pays = nq > 16 || (nq > 4 ? ix->ntotal >= 400000 : ix->ntotal >= 1200000);
+    const bool want_split = mode == CSS_SEARCH_SPLIT || env.batch == 1;   // split-operand candidate scan from the fp32 rows
     const bool want_candidates = env.batch == 0 && (mode == CSS_SEARCH_COARSE || (mode == CSS_SEARCH_AUTO && coarse_pays));
     if (want_candidates && ix->xh != nullptr) {
         if (nq <= 4)  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
@@ -1825,8 +1964,13 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
         }
         return CSS_OK;
     }
-    // no shadow rows: batches still take a candidate path, with split-operand coarse scores from the fp32 rows
-    if (batch_ok && k + kSplitExtra <= kMfmaMaxK && (env.batch == 1 || (want_candidates && ix->xh == nullptr))) {
+    // no shadow rows: batches take the same cascade over bf16 rows rounded on the fly, one row range at a time
+    // (CSS_KNN_NOSHADOW=split, a k beyond the MFMA kernels, or no HBM left for the scratch rows: the split-operand scan)
+    if (want_candidates && ix->xh == nullptr && nq > 16 && env.noshadow_ranges && ix->dpad % 128 == 0) {
+        rc = search_noshadow_ranges(ix, nq, k, D_dev, I_dev, st);
+        if (rc != CSS_ERR_STATE) return rc;
+    }
+    if (batch_ok && k + kSplitExtra <= kMfmaMaxK && (want_split || (want_candidates && ix->xh == nullptr))) {
         for (int64_t q0 = 0; q0 < nq; q0 += 4096) {   // (chunked like the bf16 cascade: candidate buffers are per query)
             const int nqc = (int)std::min<int64_t>(4096, nq - q0);
             rc = ix->metric == CSS_METRIC_IP ? launch_scan_split_rescore<CSS_METRIC_IP>(ix, (int)q0, nqc, k, D_dev, I_dev, sg, st)
@@ -1837,7 +1981,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     }
     // shadow-less batches whose k leaves no room for the split scan's extra ranks (k = 61 .. 64): the fp32-input MFMA
     // scan, not 16-query VALU sweeps
-    if (batch_ok && want_candidates && ix->xh == nullptr) {
+    if (batch_ok && (want_split || (want_candidates && ix->xh == nullptr))) {
         return ix->metric == CSS_METRIC_IP ? launch_scan_fp32mfma<CSS_METRIC_IP>(ix, (int)nq, k, D_dev, I_dev, st)
                                            : launch_scan_fp32mfma<CSS_METRIC_L2>(ix, (int)nq, k, D_dev, I_dev, st);
     }
@@ -1908,7 +2052,7 @@ int css_index_free(css_index* ix) {
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
-                    ix->qh2, ix->thr2, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB};
+                    ix->qh2, ix->thr2, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
@@ -1922,6 +2066,7 @@ int css_index_reset(css_index* ix) {
     CSS_REQUIRE(ix, "css_index_reset: NULL index");
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     ix->ntotal = 0;
+    ix->ntotal_pub.store(0);
     if (!ix->xh) ix->shadow = -1;
     DeviceGuard g(ix->device);
     if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
@@ -1942,7 +2087,7 @@ int css_index_reserve(css_index* ix, int64_t n) {
 
 int css_index_ntotal(const css_index* ix, int64_t* n) {
     CSS_REQUIRE(ix && n, "css_index_ntotal: NULL argument");
-    *n = ix->ntotal;
+    *n = ix->ntotal_pub.load();
     return CSS_OK;
 }
 
@@ -1966,7 +2111,7 @@ int css_index_device(const css_index* ix, int* device) {
 
 int css_index_set_search_mode(css_index* ix, int mode) {
     CSS_REQUIRE(ix, "css_index_set_search_mode: NULL index");
-    CSS_REQUIRE(mode == CSS_SEARCH_AUTO || mode == CSS_SEARCH_EXACT_FP32 || mode == CSS_SEARCH_COARSE,
+    CSS_REQUIRE(mode == CSS_SEARCH_AUTO || mode == CSS_SEARCH_EXACT_FP32 || mode == CSS_SEARCH_COARSE || mode == CSS_SEARCH_SPLIT,
                 "css_index_set_search_mode: unknown mode %d", mode);
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     ix->search_mode = mode;
@@ -1984,6 +2129,14 @@ int css_index_last_flagged(css_index* ix, int64_t* n) {
     int v = 0;
     CSS_HIP_TRY(hipMemcpy(&v, ix->last_nflag, sizeof(int), hipMemcpyDeviceToHost));
     *n = v;
+    return CSS_OK;
+}
+
+int css_index_set_range_rows(css_index* ix, int64_t rows) {
+    CSS_REQUIRE(ix, "css_index_set_range_rows: NULL index");
+    CSS_REQUIRE(rows >= 0, "css_index_set_range_rows: rows < 0");
+    std::unique_lock<std::shared_mutex> lk(ix->mu);
+    ix->range_rows = rows;
     return CSS_OK;
 }
 
@@ -2048,6 +2201,7 @@ int css_index_add(css_index* ix, const float* x_host, int64_t n, int normalize) 
         if ((rc = ingest(ix, ix->stage, m, normalize, false, 0, 0, ix->stream)) != CSS_OK) return rc;
         CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
         ix->ntotal += m;
+        ix->ntotal_pub.store(ix->ntotal);
     }
     return CSS_OK;
 }
@@ -2068,6 +2222,7 @@ int css_index_add_dev(css_index* ix, const float* x_dev, int64_t n, int normaliz
         if ((rc = ingest(ix, x_dev + (size_t)r0 * ix->dim, m, normalize, false, 0, 0, (hipStream_t)stream)) != CSS_OK)
             return rc;
         ix->ntotal += m;
+        ix->ntotal_pub.store(ix->ntotal);
     }
     // the rows are written asynchronously on the caller's stream: later searches / reallocations / exports wait for this
     CSS_HIP_TRY(hipEventRecord(ix->ingest_ev, (hipStream_t)stream));
@@ -2090,6 +2245,7 @@ int css_index_add_synthetic(css_index* ix, int64_t n, uint64_t seed, int64_t fir
         if ((rc = ingest(ix, nullptr, m, normalize, true, seed, first_row + r0, (hipStream_t)stream)) != CSS_OK)
             return rc;
         ix->ntotal += m;
+        ix->ntotal_pub.store(ix->ntotal);
     }
     CSS_HIP_TRY(hipEventRecord(ix->ingest_ev, (hipStream_t)stream));
     ix->ingest_pending = true;
@@ -2100,6 +2256,7 @@ int css_index_export(const css_index* cix, int64_t row0, int64_t n, float* x_out
     css_index* ix = const_cast<css_index*>(cix);
     CSS_REQUIRE(ix && x_out_host, "css_index_export: NULL argument");
     std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);   // (a search may have the index narrowed to a row range while it enqueues)
     CSS_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, "css_index_export: rows [%lld, %lld) outside [0, %lld)",
                 (long long)row0, (long long)(row0 + n), (long long)ix->ntotal);
     if (n == 0) return CSS_OK;
@@ -2182,28 +2339,6 @@ int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int 
     return css_index_search_masked(ix, q_host, nq, k, normalize_q, nullptr, D_host, I_host);
 }
 
-namespace {
-int merge_parts(const float* Dp, const int64_t* Ip, int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
-                int metric, float* D, int64_t* I, int device, void* stream, const char* who) {
-    CSS_REQUIRE(Dp && Ip && D && I, "%s: NULL buffer", who);
-    CSS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= CSS_MAX_K, "%s: bad sizes", who);
-    CSS_REQUIRE(metric == CSS_METRIC_IP || metric == CSS_METRIC_L2, "%s: unknown metric", who);
-    int rc = css::check_device(device);
-    if (rc != CSS_OK) return rc;
-    if (nq == 0) return CSS_OK;
-    DeviceGuard g(device);
-    hipStream_t st = (hipStream_t)stream;
-    ProfScope ps("knn_merge_parts", st);
-    if (metric == CSS_METRIC_IP)
-        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
-                           stride_i, nq, k, D, I);
-    else
-        hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
-                           stride_i, nq, k, D, I);
-    CSS_LAUNCH_CHECK();
-    return CSS_OK;
-}
-}  // namespace
 
 int css_merge_topk_dev(const float* Dp, const int64_t* Ip, int nparts, int64_t nq, int k, int metric, float* D,
                        int64_t* I, int device, void* stream) {

@@ -50,6 +50,20 @@ __global__ void k_rows_to_bf16(const float* __restrict__ in, unsigned short* __r
     out[i] = __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 
+// fp32 rows -> bf16 rows, 8 elements per thread (16-B stores), grid-stride: the bf16 ranges of shadow-less indexes
+// (a dispatch carries at most 2^32 work-items, a 10 M-row range has 7.7e9 elements)
+__global__ __launch_bounds__(256) void k_rows_to_bf16_x8(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n8) {
+    typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+        v8bf_t h;
+        h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+        h[4] = (__bf16)b.x; h[5] = (__bf16)b.y; h[6] = (__bf16)b.z; h[7] = (__bf16)b.w;
+        reinterpret_cast<v8bf_t*>(out)[i] = h;
+    }
+}
+
 // thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
 // the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
 // flagged query claims take part in that scan with thr2 = +inf, i.e. without ever appending

@@ -144,8 +144,9 @@ class IndexFlat:
     def set_search_mode(self, mode: str) -> None:
         """``"auto"`` (default: bf16 candidate scan + exact fp32 rescoring where the index keeps shadow
         rows and is large enough for it to pay), ``"exact_fp32"`` (every score formed in fp32 by the
-        scan kernels) or ``"coarse"`` (the candidate path whatever the index size)."""
-        modes = {"auto": 0, "exact_fp32": 1, "coarse": 2}
+        scan kernels), ``"coarse"`` (the candidate path whatever the index size) or ``"split"`` (batches: candidates
+        from split-operand products of the fp32 rows, the fallback of shadow-less indexes; verification)."""
+        modes = {"auto": 0, "exact_fp32": 1, "coarse": 2, "split": 3}
         if mode not in modes:
             raise ValueError(f"unknown search mode {mode!r}")
         nat.check(nat.lib().css_index_set_search_mode(self._handle(), modes[mode]))
@@ -168,6 +169,11 @@ class IndexFlat:
         fit (default), ``False`` = never, ``True`` = always.  Only on an empty index; results do not change."""
         p = -1 if policy is None else (1 if policy else 0)
         nat.check(nat.lib().css_index_set_shadow(self._handle(), p))
+
+    def set_range_rows(self, rows: int) -> None:
+        """Shadow-less indexes: rows per bf16 scratch range of a batched search (0 = automatic); results do not
+        depend on it."""
+        nat.check(nat.lib().css_index_set_range_rows(self._handle(), int(rows)))
 
     def set_id_base(self, base: int) -> None:
         nat.check(nat.lib().css_index_set_id_base(self._handle(), int(base)))

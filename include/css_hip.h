@@ -112,7 +112,8 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * Indexes keep a bf16 shadow copy of the rows while it fits in HBM; searches
  * of large indexes then select candidates with a bf16 scan inside a rigorous
  * error band and return exact fp32 scores of the rescored candidates (same
- * results as the fp32 kernels).  The _dev form only enqueues on `stream` and never
+ * results as the fp32 kernels).  Without shadow rows, batches round the rows to
+ * bf16 one row range at a time into scratch memory and run the same scan per range.  The _dev form only enqueues on `stream` and never
  * waits for the device: queries whose candidate band overflows are re-run exactly by
  * two launches that follow every cascade and return at once when there are none.
  * Rows appended by css_index_add_dev / css_index_add_synthetic on another stream are
@@ -131,7 +132,13 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
 #define CSS_SEARCH_AUTO 0
 #define CSS_SEARCH_EXACT_FP32 1
 #define CSS_SEARCH_COARSE 2 /* the candidate path whatever the index size (AUTO uses it only where it pays) */
+#define CSS_SEARCH_SPLIT 3  /* batches of > 16 queries: candidates from split-operand (bf16 pair) products of the fp32 rows +
+                               fp32 rescoring -- what an index without shadow rows falls back to when no HBM is left for
+                               the scratch rows of its bf16 ranges; selectable for verification */
 int css_index_set_search_mode(css_index* ix, int mode);
+/* Indexes without shadow rows: rows per bf16 scratch range of a batched search (0 = automatic: half of the free HBM,
+ * at most 2^24 rows).  A tuning / verification knob: results do not depend on it. */
+int css_index_set_range_rows(css_index* ix, int64_t rows);
 int css_index_search(css_index* ix, const float* q_host, int64_t nq, int k, int normalize_q,
                      float* D_host, int64_t* I_host);
 int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,

@@ -271,3 +271,25 @@ def test_10m_clustered_rows_second_pass_matches_the_cpu_oracle():
     Da, Ia = ix.search(q[:1], K, normalize=True)
     assert_topk_matches(Da, Ia, Dr[:1, :K], Ir[:1, :K], D64[:1, :K], "10M clustered nq=1", D64_next=D64[:1, K])
     ix.close()
+
+
+def test_10m_index_without_shadow_rows_answers_like_the_shadowed_one(big_index):
+    """An index without bf16 shadow rows (the state of a shard beyond ~38 M rows per GPU) rounds its rows to bf16 one
+    row range at a time and runs the cascade of shadowed indexes per range: at 10 M rows (7.7e9 elements: beyond one
+    dispatch's 2^32 work-items, which an earlier version of the conversion kernel silently truncated) the batched
+    answers must be those of the shadowed index over the same rows -- same bf16 values, same error band, same fp32
+    rescoring -- with one range and with three merged ranges."""
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    q = synth.rows(300, D, 5)
+    Dref, Iref = big_index.search(q, K, normalize=True)
+    ix = IndexFlatIP(D)
+    ix.set_shadow(False)
+    ix.reserve(N)
+    ix.add_synthetic(N, seed=4, first_row=0, normalize=True)
+    for rows in (0, 4_000_000):
+        ix.set_range_rows(rows)
+        Dn, In = ix.search(q, K, normalize=True)
+        assert np.array_equal(In, Iref) and np.array_equal(Dn, Dref), rows
+    ix.close()

@@ -481,18 +481,70 @@ def test_no_shadow_batches_match_oracle(n, nq, k, metric):
     ref.add(xr)
     Dr, Ir = ref.search(qr, k)
     D64 = ref.rescore64(qr, Ir)
-    for mode, scope in (("auto", "knn_split_cascade"), ("coarse", "knn_split_cascade"), ("exact_fp32", "knn_scan_mfma")):
+    # auto / coarse: bf16 rows rounded on the fly, range by range, through the cascade of shadowed indexes; split: the
+    # split-operand scan (the fallback when no scratch memory is left); exact_fp32: the fp32-input MFMA scan
+    for mode, scope in (("auto", "knn_noshadow_ranges"), ("coarse", "knn_noshadow_ranges"), ("split", "knn_split_cascade"),
+                        ("exact_fp32", "knn_scan_mfma")):
         ix.set_search_mode(mode)
         nat.prof_reset()
         nat.prof_enable(True)
         D, I = ix.search(q, k, normalize=norm)
         nat.prof_enable(False)
         assert nat.prof_read(scope)[1] == 1, f"[{mode}] expected the {scope} path"
-        assert nat.prof_read("knn_coarse_cascade")[1] == 0
+        assert (nat.prof_read("knn_coarse_cascade")[1] >= 1) == (scope == "knn_noshadow_ranges")
+        assert (nat.prof_read("knn_split_cascade")[1] >= 1) == (scope == "knn_split_cascade")
         assert_topk_matches(D, I, Dr, Ir, D64, f"no shadow [{mode}] n={n} nq={nq} k={k} metric={metric}")
     nat.prof_reset()
     with pytest.raises(RuntimeError):
         ix.set_shadow(True)      # only on an empty index
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_no_shadow_row_ranges_merge_like_one_index(metric):
+    """Shadow-less batches round the rows to bf16 one row range at a time and merge the per-range top-k lists: 70 000
+    rows in ranges of 16 384 (5 ranges, the last one ragged), 2 500 rows (one range), a masked search across the
+    ranges and id_base, against the oracle; the answers must not depend on the range size."""
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlat
+
+    norm = metric == 0
+    n, nq, k = 70_000, 130, 10
+    x = synth.rows(n, 768, 501)
+    q = synth.rows(nq, 768, 502)
+    ix = IndexFlat(768, metric)
+    ix.set_shadow(False)
+    ix.add(x, normalize=norm)
+    ix.set_id_base(1000)
+    ref = ko.FlatIndexOracle(768, metric)
+    xr, qr = (ko.normalize_rows(x), ko.normalize_rows(q)) if norm else (x, q)
+    ref.add(xr)
+    Dr, Ir = ref.search(qr, k)
+    D64 = ref.rescore64(qr, Ir)
+    got = []
+    for rows in (16_384, 0):
+        ix.set_range_rows(rows)
+        nat.prof_reset()
+        nat.prof_enable(True)
+        D, I = ix.search(q, k, normalize=norm)
+        nat.prof_enable(False)
+        assert nat.prof_read("knn_noshadow_ranges")[1] == 1
+        assert nat.prof_read("knn_rows_to_bf16")[1] == (5 if rows else 1)
+        assert nat.prof_read("knn_merge_parts")[1] == (1 if rows else 0)
+        assert_topk_matches(D, I - 1000, Dr, Ir, D64, f"no shadow, ranges of {rows} rows, metric={metric}")
+        got.append((D, I))
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][0], got[1][0])
+    nat.prof_reset()
+    # masked: only rows whose number is 1 mod 3 (bitmap in local row numbering, cut at range boundaries)
+    allow = (np.arange(n) % 3) == 1
+    ix.set_range_rows(16_384)
+    Dm, Im = ix.search(q, k, normalize=norm, allow=allow)
+    sub = np.flatnonzero(allow)
+    o = ko.FlatIndexOracle(768, metric)
+    o.add(xr[sub])
+    Ds, Is = o.search(qr, k)
+    assert_topk_matches(Dm, Im - 1000, Ds, sub[Is], o.rescore64(qr, Is), f"no shadow, masked, metric={metric}")
     ix.close()
 
 
@@ -509,6 +561,7 @@ def test_no_shadow_large_batches_are_chunked_and_k_above_60_takes_the_mfma_scan(
     ix = IndexFlatIP(768)
     ix.set_shadow(False)
     ix.add(x, normalize=True)
+    ix.set_search_mode("split")
     ref = ko.FlatIndexOracle(768, 0)
     ref.add(ko.normalize_rows(x))
     q = synth.rows(4096 + 4096 + 130, 768, 312)            # two full chunks + a ragged one
@@ -543,6 +596,7 @@ def test_no_shadow_band_beyond_the_kept_ranks_is_fixed_up():
     ix = IndexFlatIP(768)
     ix.set_shadow(False)
     ix.add(x, normalize=True)
+    ix.set_search_mode("split")
     nat.prof_reset()
     nat.prof_enable(True)
     D, I = ix.search(q, 10, normalize=True)

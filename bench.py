@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-heavy-extra", action="store_true", help="skip the extras that build further 10 M-row indexes (counter passes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work")
     ap.add_argument("--enc-batch", type=int, default=256, help="encoder batch (sequences)")
     ap.add_argument("--enc-len", type=int, default=384, help="encoder sequence length (tokens)")
@@ -825,7 +826,7 @@ def _main(argv, platform_factory):
             extra["clustered_1M"] = bench_clustered(args, dev, stream, log)
         except Exception as ex_:   # an extra: never fail the bench line over it
             extra["clustered_1M"] = {"error": repr(ex_)}
-        if args.rows >= 10_000_000:
+        if args.rows >= 10_000_000 and not args.no_heavy_extra:
             index.close()   # (46 GB back before three more 10 M-row indexes are built, one at a time)
             try:   # an index without bf16 shadow rows (what a > 38 M-row shard gets): ranges of on-the-fly bf16 rows vs the split-operand scan
                 extra["no_shadow_10M"] = bench_no_shadow(args, dev, stream, log)

@@ -55,6 +55,7 @@ struct EncEnv {
     bool fuse_ln = true;     // CSS_ENC_FUSE_LN=0: separate LayerNorm kernels also for large batches
     float att_range = -1.f;  // CSS_ATT_RANGE: default of css_encoder_set_attention_range (0 = always the safe softmax pass)
     int cg_qkv = 0, cg_ffn1 = 0, cg_o = 0, cg_ffn2 = 0;   // CSS_GEMM_CG="qkv,ffn1,o,ffn2": column-group tile walk of k_gemm8p (0 = N-fastest)
+    int grid_qkv = 0, grid_ffn1 = 0, grid_o = 0, grid_ffn2 = 0;   // CSS_GEMM_GRID="qkv,ffn1,o,ffn2": blocks of k_gemm8p (0 = automatic)
     EncEnv() {
         if (const char* t = getenv("CSS_GEMM_TILE")) big_tiles = atoi(t) != 128;
         if (const char* t = getenv("CSS_GEMM_DBG")) dbg = atoi(t);
@@ -64,6 +65,7 @@ struct EncEnv {
         if (const char* t = getenv("CSS_ENC_FUSE_LN")) fuse_ln = atoi(t) != 0;
         if (const char* t = getenv("CSS_ATT_RANGE")) att_range = (float)atof(t);
         if (const char* t = getenv("CSS_GEMM_CG")) sscanf(t, "%d,%d,%d,%d", &cg_qkv, &cg_ffn1, &cg_o, &cg_ffn2);
+        if (const char* t = getenv("CSS_GEMM_GRID")) sscanf(t, "%d,%d,%d,%d", &grid_qkv, &grid_ffn1, &grid_o, &grid_ffn2);
     }
 };
 const EncEnv& enc_env() {
@@ -342,7 +344,7 @@ int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int 
     int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);
     if (rc_ != CSS_OK) return rc_;
     const int ntiles = (N / 256) * ((M + 255) / 256);
-    int grid = std::min(ntiles, num_cus);
+    int grid = std::min(ntiles, side.grid > 0 ? std::min(side.grid, num_cus) : num_cus);
     grid = std::max(8, grid / 8 * 8);
     ProfScope ps(prof, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K,
@@ -503,6 +505,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.stats_in = e->stats[0];
         side.stats_out = e->stats[1];
         side.cgroup = enc_env().cg_qkv;
+        side.grid = enc_env().grid_qkv;
         if ((rc = launch_gemm8p<EPI_AFF_QKV>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
                                              side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
@@ -518,18 +521,21 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.pprev = pre[0];
         side.cvec = g_in;
         side.cgroup = enc_env().cg_o;
+        side.grid = enc_env().grid_o;
         if ((rc = launch_gemm8p<EPI_RES>(e->ctx, L.wo_h, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
         side.stats_in = e->stats[1];
         side.stats_out = e->stats[0];
         side.cgroup = enc_env().cg_ffn1;
+        side.grid = enc_env().grid_ffn1;
         if ((rc = launch_gemm8p<EPI_AFF_GELU>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         // pre[0] = ffn W2^T + (b2 + beta1) + gamma1 (pre[1] - mu) rs; stats[0] += row sums
         side.pprev = pre[1];
         side.cvec = L.ln1g;
         side.cgroup = enc_env().cg_ffn2;
+        side.grid = enc_env().grid_ffn2;
         if ((rc = launch_gemm8p<EPI_RES>(e->ffn, L.w2_h, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         g_in = L.ln2g;

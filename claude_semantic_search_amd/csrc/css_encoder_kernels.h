@@ -810,6 +810,7 @@ struct G8Side {
     float inv_h;             // 1 / hidden
     float eps;
     int cgroup;              // > 0: tile walk in column groups of `cgroup` tile columns (see G8_TILE)
+    int grid;                // host side only: blocks to launch (0 = one per CU)
 };
 #if defined(G8_EXP) && (G8_EXP & 16)
 #define G8_SIDE_WAVES 2

@@ -11,12 +11,12 @@ timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "[profile] bench done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- python3 bench.py > $O/bench_under_rocprof.json 2> $O/stats.err || exit 2
 echo "[profile] stats done"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --enc-steps 2 > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 3
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-heavy-extra --enc-steps 2 > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 3
 echo "[profile] fetch done"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --enc-steps 2 > $O/pmc_write.json 2> $O/pmc_write.err || exit 4
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-heavy-extra --enc-steps 2 > $O/pmc_write.json 2> $O/pmc_write.err || exit 4
 echo "[profile] write done"
 python3 tools/pmc_summarise.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json \
-  --note "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --enc-steps 2" \
+  --note "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-heavy-extra --enc-steps 2" \
   --workload '{"rows_per_gpu": 10000000, "dim": 768, "nq": 1000, "k": 10}'
 # encoder alone at its fixed 256 x 384 shape (per-forward HBM traffic = sum over its kernels / forwards)
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_enc -o run --output-format csv -- python3 bench.py --only-encoder --enc-fixed-only --no-cpu-baseline --enc-steps 3 > $O/pmc_fetch_enc.json 2> $O/pmc_fetch_enc.err || exit 5

@@ -27,8 +27,8 @@ while time.time() - t0 < secs:
     if kind == "clustered":
         c = synth.rows(max(2, n // 300), d, seed + 1)
         x = c[np.arange(n) % c.shape[0]] + 0.03 * x
-    elif kind == "dups":
-        x[n // 3: n // 3 + min(n // 4, 7000)] = x[7]
+    elif kind == "dups":   # > 4096 copies: flagged -> second coarse pass; > 32768: on to the exact sweep
+        x[n // 3: n // 3 + min(n // 4, int(rng.choice([7000, 7000, 40_000])))] = x[7]
     elif kind == "wide_norms":
         x = x * np.exp(rng.normal(0, 0.7, size=(n, 1))).astype(np.float32)
     nq = int(rng.choice([1, 2, 4, 7, 16, 40, 255, 256, 700]))
@@ -40,26 +40,32 @@ while time.time() - t0 < secs:
     ix = IndexFlat(d, metric)
     noshadow = rng.random() < 0.2
     if noshadow:
-        ix.set_shadow(0)      # candidate scores from the fp32 rows (split operands) + fp32 rescoring
+        ix.set_shadow(0)      # batches: bf16 rows rounded range by range into scratch memory ("coarse"), or split operands ("split")
+        ix.set_range_rows(int(rng.choice([0, 0, 4096, 33_000])))
     ix.add(x, normalize=norm)
     res = {}
-    for mode in ("exact_fp32", "coarse"):
+    for mode in ("exact_fp32", "coarse") + (("split",) if noshadow and rng.random() < 0.5 else ()):
         ix.set_search_mode(mode)
         res[mode] = ix.search(q, k, normalize=norm, allow=allow) if allow is not None else ix.search(q, k, normalize=norm)
     De, Ie = res["exact_fp32"]
-    Dc, Ic = res["coarse"]
-    tag = f"it={it} d={d} n={n} metric={metric} norm={norm} kind={kind} nq={nq} k={k} masked={allow is not None} noshadow={noshadow} seed={seed}"
+    tag0 = f"it={it} d={d} n={n} metric={metric} norm={norm} kind={kind} nq={nq} k={k} masked={allow is not None} noshadow={noshadow} seed={seed}"
     valid = Ie >= 0
-    assert ((Ic >= 0) == valid).all(), "padding differs: " + tag
     scale = max(1.0, float(np.abs(De[valid]).max())) if valid.any() else 1.0
-    assert np.allclose(Dc[valid], De[valid], atol=2e-5 * scale, rtol=0), f"scores differ by {np.abs(Dc[valid] - De[valid]).max()}: " + tag
     gaps = np.abs(np.diff(De.astype(np.float64), axis=1))
     safe = valid.copy()
     safe[:, 1:] &= gaps > 1e-5 * scale
     safe[:, :-1] &= gaps > 1e-5 * scale
     safe[:, -1] = False          # the rank behind the last slot is unknown
-    bad = safe & (Ic != Ie)
-    assert not bad.any(), f"{int(bad.sum())} id mismatches: " + tag
+    for mode in res:
+        if mode == "exact_fp32":
+            continue
+        Dc, Ic = res[mode]
+        tag = f"[{mode}] " + tag0
+        assert ((Ic >= 0) == valid).all(), "padding differs: " + tag
+        assert np.allclose(Dc[valid], De[valid], atol=2e-5 * scale, rtol=0), f"scores differ by {np.abs(Dc[valid] - De[valid]).max()}: " + tag
+        bad = safe & (Ic != Ie)
+        assert not bad.any(), f"{int(bad.sum())} id mismatches: " + tag
+    tag = tag0
     ix.close()
     it += 1
     if it % 20 == 0:

@@ -65,6 +65,8 @@ class ShardedFlatIndex:
             index_factory = lambda: IndexFlat(self.d, self.metric, device=device_index or 0)  # noqa: E731
         self.local = index_factory()
         self._merge = merge      # None: the HIP merge straight from the packed exchange buffer
+        #: run the all-gather + merge even with ONE rank (tests: the RCCL calls of the N > 1 path on a one-GPU box)
+        self.exchange_when_single = False
         self.ntotal_global = 0
         self.shard_sizes = [0] * self.world          # replicated bookkeeping (all adds are collective calls)
         self.segments: List[Tuple[int, int, int]] = []   # (local_row0, global_row0, n) of THIS shard
@@ -173,7 +175,7 @@ class ShardedFlatIndex:
             I.copy_(torch.from_numpy(i_np))
         if len(self.segments) > 1:
             I.copy_(self._to_global(I))
-        if self.world == 1:
+        if self.world == 1 and not self.exchange_when_single:
             return D, I
         # THE exchange step of the path: one all-gather of nq*k*12 bytes per rank
         recv_flat = torch.empty(self.world * record, dtype=torch.uint8, device=q.device)

@@ -118,3 +118,51 @@ def test_flagged_query_count_is_reported():
     ix.search(synth.rows(30, 768, 74), 10, normalize=True)
     assert ix.last_flagged() <= 1
     ix.close()
+
+
+def _nccl_single_rank(port, out_path):
+    """The RCCL calls of the N > 1 path with ONE rank (all a one-GPU box allows: RCCL refuses two ranks on one
+    device): init_process_group("nccl", device_id=...), barrier(device_ids=...), all_reduce of a device tensor, and the
+    search's all_gather_into_tensor of a device uint8 record + the HIP merge that reads it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.sharded import ShardedFlatIndex
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        dist.barrier(device_ids=[0])
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 3.5
+        sh = ShardedFlatIndex(768, 0, device_index=0)
+        sh.add_synthetic_global(30_000, seed=4, normalize=True, stream=torch.cuda.current_stream().cuda_stream)
+        q = torch.from_numpy(synth.rows(9, 768, 5)).to(dev)
+        D0, I0 = sh.search_tensors(q, 10, normalize=True)          # world 1: no exchange
+        D0, I0 = D0.clone(), I0.clone()
+        sh.exchange_when_single = True
+        D1, I1 = sh.search_tensors(q, 10, normalize=True)          # packed all-gather over RCCL + packed merge
+        torch.cuda.synchronize()
+        assert torch.equal(I0, I1) and torch.equal(D0, D1)
+        dist.barrier(device_ids=[0])
+        open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_calls_of_the_sharded_path_run_with_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "ok.txt"
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_single_rank, args=(port, str(out)))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0 and out.read_text() == "ok"

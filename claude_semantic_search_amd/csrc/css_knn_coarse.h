@@ -1026,6 +1026,62 @@ __device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int
 // best score for the second pass, and any subset of rows gives one.
 constexpr int CZ_PARTS = 16;
 constexpr int CZ_FLAGGED_RESCORE = 512;
+// k-th largest of s[0 .. n) (n >= k) by a most-significant-digit radix selection over order-preserving 32-bit keys: four
+// passes of an 8-bit LDS histogram + one wave's suffix scan over the 256 bins.  The stage selects need the k-th best
+// coarse score and the entries above a threshold derived from it, not an ordering: the full bitonic sort they used
+// until round 3 (78 barrier-separated rounds at 4096 entries) was 15-35 us of every select and, with one block per
+// query, 0.35 ms of the 2.8 ms single-query search (7 selects in a row).  Block of 256 threads; hist: 256 words of LDS.
+__device__ __forceinline__ float cz_kth_largest(const float* s, int n, int k, unsigned* hist, int* sel, int tid) {
+    unsigned prefix = 0, mask = 0;
+    int kk = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const unsigned u = (unsigned)f2key(s[i]) ^ 0x80000000u;   // unsigned order = float order
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // lane l owns bins 255 - 4 l .. 252 - 4 l; cum = keys in its bins and all higher ones
+            const int b0 = 255 - 4 * tid;
+            const unsigned c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+            const unsigned tot = (c0 + c1) + (c2 + c3);
+            unsigned cum = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_up((int)cum, o);
+                if (tid >= o) cum += v;
+            }
+            const unsigned long long hit = __ballot(cum >= (unsigned)kk);   // (never empty: the candidates of this pass number >= kk)
+            if (tid == __ffsll((long long)hit) - 1) {
+                unsigned a = cum - tot;
+                int bsel = b0;
+                if (a + c0 < (unsigned)kk) {
+                    a += c0;
+                    bsel = b0 - 1;
+                    if (a + c1 < (unsigned)kk) {
+                        a += c1;
+                        bsel = b0 - 2;
+                        if (a + c2 < (unsigned)kk) {
+                            a += c2;
+                            bsel = b0 - 3;
+                        }
+                    }
+                }
+                sel[0] = bsel;
+                sel[1] = (int)a;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 0xFFu << shift;
+        kk -= sel[1];
+        __syncthreads();
+    }
+    return key2f((int)(prefix ^ 0x80000000u));
+}
+
 template <bool FINAL>
 __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                        int* __restrict__ cand_n, float* __restrict__ thr,
@@ -1037,41 +1093,50 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                                                        int* __restrict__ fix_lock) {
     __shared__ float s[CZ_CAP];
     __shared__ uint32_t id[CZ_CAP];
+    __shared__ unsigned hist[256];
+    __shared__ int sel[2];
     __shared__ int cnt;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int n_raw = cand_n[q];
     const bool overflow = n_raw > CZ_CAP;
     const int n = min(n_raw, CZ_CAP);
-    int P = 2;
-    while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 256) {
-        s[i] = i < n ? cand_s[(size_t)q * CZ_CAP + i] : -INFINITY;
-        id[i] = i < n ? cand_i[(size_t)q * CZ_CAP + i] : kInvalidRow;
+    for (int i = tid; i < n; i += 256) {
+        s[i] = cand_s[(size_t)q * CZ_CAP + i];
+        id[i] = cand_i[(size_t)q * CZ_CAP + i];
     }
     if (tid == 0) cnt = 0;
-    cz_bitonic(s, id, P, tid);
-    const float Tc = n >= k ? s[k - 1] : -INFINITY;
+    __syncthreads();
+    const float Tc = n >= k ? cz_kth_largest(s, n, k, hist, sel, tid) : -INFINITY;
     const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(*maxn2_bits), l2);
     const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
-    int c = 0;
-    for (int i = tid; i < n; i += 256) c += (s[i] >= thr_new && id[i] != kInvalidRow) ? 1 : 0;
-    if (c) atomicAdd(&cnt, c);
-    __syncthreads();
-    const int m = cnt;  // the band is a prefix of the sorted buffer
-    if constexpr (!FINAL) {
-        for (int i = tid; i < m; i += 256) {
-            cand_s[(size_t)q * CZ_CAP + i] = s[i];
-            cand_i[(size_t)q * CZ_CAP + i] = id[i];
+    bool bad = false;
+    if constexpr (FINAL) {
+        // closed_n > 0 (split-operand scan, which keeps only its closed_n best scores): a band that reaches the last
+        // kept rank may continue beyond it -- decided on the count, below; buffer overflows are known already
+        bad = overflow || flags[q] != 0;
+    }
+    if (!bad) {
+        // the band, compacted in place of the buffer (in arrival order of the LDS counter: nothing downstream depends
+        // on the order -- the next select takes a k-th largest again, the final sort is by exact score and id)
+        for (int i = tid; i < n; i += 256) {
+            if (s[i] >= thr_new && id[i] != kInvalidRow) {
+                const int pos = atomicAdd(&cnt, 1);
+                cand_s[(size_t)q * CZ_CAP + pos] = s[i];
+                cand_i[(size_t)q * CZ_CAP + pos] = id[i];
+            }
         }
+        __syncthreads();
+    }
+    const int m = cnt;
+    if constexpr (!FINAL) {
         if (tid == 0) {
             cand_n[q] = m;
             thr[q] = thr_new;
             if (overflow) flags[q] = 1;
         }
     } else {
-        // closed_n > 0 (split-operand scan, which keeps only its closed_n best scores): a band that reaches the
-        // last kept rank may continue beyond it
-        const bool bad = overflow || flags[q] != 0 || m > CZ_RMAX || (closed_n > 0 && m >= closed_n);
+        if (!bad && closed_n > 0 && m >= closed_n) bad = true;   // (m > CZ_RMAX cannot happen: the band is part of the buffer)
+        int R = m;
         if (bad) {
             // the exact fix-up (k_scan_small<FIX>), should the query get that far, starts its global list, threshold
             // and lock from scratch
@@ -1079,11 +1144,28 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                 fix_s[(size_t)q * k + i] = -INFINITY;
                 fix_i[(size_t)q * k + i] = kInvalidRow;
             }
-        }
-        const int R = bad ? min(m, CZ_FLAGGED_RESCORE) : m;
-        for (int i = tid; i < R; i += 256) {
-            cand_s[(size_t)q * CZ_CAP + i] = s[i];
-            cand_i[(size_t)q * CZ_CAP + i] = id[i];
+            // a flagged query hands its CZ_FLAGGED_RESCORE best buffered candidates to the rescoring (the tighter the
+            // bound they give, the fewer rows the second pass collects): the one case that still sorts
+            int P = 2;
+            while (P < n) P <<= 1;
+            for (int i = n + tid; i < P; i += 256) {
+                s[i] = -INFINITY;
+                id[i] = kInvalidRow;
+            }
+            cz_bitonic(s, id, P, tid);   // (starts and ends with a block barrier)
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+            int c = 0;
+            for (int i = tid; i < min(n, CZ_FLAGGED_RESCORE); i += 256) {
+                if (s[i] >= thr_new && id[i] != kInvalidRow) {   // (the band is a prefix of the sorted buffer)
+                    cand_s[(size_t)q * CZ_CAP + i] = s[i];
+                    cand_i[(size_t)q * CZ_CAP + i] = id[i];
+                    ++c;
+                }
+            }
+            if (c) atomicAdd(&cnt, c);
+            __syncthreads();
+            R = cnt;
         }
         if (tid == 0) {
             cand_n[q] = R;

@@ -150,11 +150,20 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
-                        for (int r = 0; r < NR; ++r) {                                                                 \
-                            const int ro = CZ_ROFF(n, r);                                                              \
-                            const bool ok = row0 + ro < ntotal && CZ_ALLOWED(mask, row0 + ro);                         \
-                            cand_s[qb + ro] = ok ? acc[m][n][r] : -INFINITY;                                           \
-                            cand_i[qb + ro] = ok ? (uint32_t)(row0 + ro) : kInvalidRow;                                \
+                        for (int rg = 0; rg < NR / 4; ++rg) { /* registers 4 rg .. 4 rg + 3 are 4 consecutive rows: 16-B stores */ \
+                            const int ro = CZ_ROFF(n, 4 * rg);                                                         \
+                            float4 sv_;                                                                                \
+                            uint4 iv_;                                                                                 \
+                            float* svp_ = &sv_.x;                                                                      \
+                            unsigned* ivp_ = &iv_.x;                                                                   \
+_Pragma("unroll")                                                                                                      \
+                            for (int e = 0; e < 4; ++e) {                                                              \
+                                const bool ok = row0 + ro + e < ntotal && CZ_ALLOWED(mask, row0 + ro + e);             \
+                                svp_[e] = ok ? acc[m][n][4 * rg + e] : -INFINITY;                                      \
+                                ivp_[e] = ok ? (uint32_t)(row0 + ro + e) : kInvalidRow;                                \
+                            }                                                                                          \
+                            *reinterpret_cast<float4*>(cand_s + qb + ro) = sv_;                                        \
+                            *reinterpret_cast<uint4*>(cand_i + qb + ro) = iv_;                                         \
                         }                                                                                              \
                 }                                                                                                      \
             } else {                                                                                                   \

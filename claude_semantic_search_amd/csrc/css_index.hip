@@ -55,13 +55,14 @@ struct css_index {
     int search_mode = CSS_SEARCH_AUTO;
     const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
     uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
-    int* maxn2 = nullptr;          // device scalar: bits of max ||row||^2 (coarse error bound)
+    int* maxn2 = nullptr;          // device, 2 words: bits of max ||row||^2 and of max ||row - bf16(row)||^2 (cz_eps)
     hipStream_t stream = nullptr;
     int num_cus = 256;
     // reusable workspaces (grown on demand, guarded by ws_mu)
     float* q_raw = nullptr;   size_t q_raw_cap = 0;     // floats
     float* qpad = nullptr;    size_t qpad_cap = 0;      // floats
     float* qnorm2 = nullptr;  size_t qnorm2_cap = 0;    // floats
+    float* qerr2 = nullptr;   size_t qerr2_cap = 0;     // per query: ||q - bf16(q)||^2 (cz_eps)
     unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
@@ -81,6 +82,7 @@ struct css_index {
     // second coarse pass over flagged queries (launch_scan_coarse): up to kF2Max slots with CZ_CAP2 candidates each
     unsigned short* qh2 = nullptr; size_t qh2_cap = 0;   // bf16 rows of the flagged queries
     float* thr2 = nullptr;    size_t thr2_cap = 0;
+    int* rs_work = nullptr;   size_t rs_work_cap = 0;   // [count | (query, part) items] of the band rescoring
     int* cand_n2 = nullptr;   size_t cand_n2_cap = 0;
     float* cand_s2 = nullptr; size_t cand_s2_cap = 0;
     uint32_t* cand_i2 = nullptr; size_t cand_i2_cap = 0;
@@ -128,7 +130,8 @@ template <bool SYNTH>
 __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ src, float* __restrict__ dst,
                                                      float* __restrict__ norm2, int64_t n, int dim, int dpad,
                                                      int normalize, uint64_t seed, int64_t first_row,
-                                                     unsigned short* __restrict__ dsth, int* __restrict__ maxn2) {
+                                                     unsigned short* __restrict__ dsth, int* __restrict__ maxn2,
+                                                     float* __restrict__ err2_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
     // reference: x / (||x||_2 + 1e-8)  (src/storage.py:349-350, :426)
     const float nrm = sqrtf(ss) + 1e-8f;
     float* d = dst + row * (int64_t)dpad;
-    float s2 = 0.f;
+    float s2 = 0.f, e2 = 0.f;
     for (int c = lane; c < dpad; c += 64) {
         float v = 0.f;
         if (c < dim) {
@@ -151,11 +154,19 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
             if (normalize) v = v / nrm;
         }
         d[c] = v;
-        if (dsth) dsth[row * (int64_t)dpad + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        const __bf16 h = (__bf16)v;   // the rounding every bf16 copy of this row uses (shadow rows, k_rows_to_bf16*)
+        if (dsth) dsth[row * (int64_t)dpad + c] = __builtin_bit_cast(unsigned short, h);
         s2 = fmaf(v, v, s2);
+        const float dv = v - (float)h;   // exact in fp32
+        e2 = fmaf(dv, dv, e2);
     }
     s2 = wave_allsum(s2);
+    e2 = wave_allsum(e2);
     if (lane == 0 && norm2) norm2[row] = s2;
+    // ||row - bf16(row)||^2: what the rounding actually cost (cz_eps: the measured error band of the candidate scans)
+    if (lane == 0 && err2_out) err2_out[row] = e2;
+    if (lane == 0 && maxn2 && e2 > __int_as_float(__hip_atomic_load(maxn2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        atomicMax(maxn2 + 1, __float_as_int(e2));
     // running max of ||row||^2 (non-negative floats order like their bit patterns); rows are ~unit
     // norm in the product, so after the first few rows almost no atomic is issued
     if (lane == 0 && maxn2 && s2 > __int_as_float(__hip_atomic_load(maxn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -1097,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
             cs_out[(size_t)q * CZ_CAP + i] = id == kInvalidRow ? -INFINITY : fs[i];
             ci_out[(size_t)q * CZ_CAP + i] = id;
         }
-        if (tid == 0) cn_out[q] = k;
+        if (tid == 0) cn_out[(size_t)q * CZ_NS] = k;
         return;
     }
     for (int i = tid; i < k; i += 256) {
@@ -1242,10 +1253,10 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
     unsigned short* dh = ix->xh ? ix->xh + (size_t)ix->ntotal * ix->dpad : nullptr;
     if (synth)
         hipLaunchKernelGGL(k_ingest_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, nullptr, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2);
+                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2, (float*)nullptr);
     else
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x_dev, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2);
+                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2, (float*)nullptr);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1253,6 +1264,7 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 // ---- environment switches (experiments and verification): read once, never written afterwards
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
+    bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 4;       // CSS_KNN_GROWTH=8: growth factor of the nested row sample (batched MFMA cascade)
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
@@ -1266,6 +1278,7 @@ const KnnEnv& knn_env() {
     static const KnnEnv env = [] {
         KnnEnv e;
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
+        if (const char* m = getenv("CSS_KNN_EPS")) e.eps_measured = strcmp(m, "apriori") != 0;
         if (const char* m = getenv("CSS_KNN_GROWTH")) e.growth = atoi(m) == 8 ? 8 : 4;
         if (const char* m = getenv("CSS_KNN_GROWTH_SWEEP")) {
             const int v = atoi(m);
@@ -1395,7 +1408,8 @@ int launch_fixup(css_index* ix, const float* qpad, int nq, int k, int* gthr, con
 int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
     int rc;
     if ((rc = grow(&ix->cthr, &ix->cthr_cap, nq_pad)) != CSS_OK) return rc;
-    if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, nq_pad)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cand_n, &ix->cand_n_cap, (size_t)nq_pad * CZ_NS)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->rs_work, &ix->rs_work_cap, 1 + (size_t)nq_pad * CZ_PARTS)) != CSS_OK) return rc;
     ix->last_nflag = nullptr;
     ix->last_nswept = nullptr;
     if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 1)) != CSS_OK) return rc;
@@ -1472,16 +1486,17 @@ int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_
 // After the last stage of a candidate scan: band cut + flagging (one block per query), exact rescoring of the bands
 // (CZ_PARTS work items per query over a fixed grid), sort by exact score + output (one block per query).
 constexpr int kRescoreGrid = 4096;
-int launch_final_select(css_index* ix, int nq, int k, float eps_rel, int l2, int closed_n, const float* qpad, const float* qnorm2,
-                        int* gthr, int* flags, int* nflag, int* flag_list, float* D_dev, int64_t* I_dev, float* thr2,
+int launch_final_select(css_index* ix, int nq, int k, float eps_rel, const float* qerr2, int measured, int l2, int closed_n,
+                        const float* qpad, const float* qnorm2, int* gthr, int* flags, int* nflag, int* flag_list, float* D_dev, int64_t* I_dev, float* thr2,
                         unsigned short* qh2, int f2, hipStream_t st) {
     hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr, flags,
-                       nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, ix->fix_s, ix->fix_i, ix->fix_lock);
+                       nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, qerr2, measured, ix->fix_s, ix->fix_i, ix->fix_lock);
+    hipLaunchKernelGGL(k_rescore_plan, dim3(1), dim3(1024), 0, st, (const int*)ix->cand_n, nq, ix->rs_work, ix->rs_work + 1);
     hipLaunchKernelGGL(k_rescore_parts<false>, dim3(std::min(kRescoreGrid, nq * CZ_PARTS)), dim3(256), 0, st, ix->cand_s,
                        ix->cand_i, ix->cand_n, CZ_CAP, nq, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, l2, qpad,
-                       ix->xb, ix->dpad);
+                       ix->xb, ix->dpad, (const int*)ix->rs_work, (const int*)(ix->rs_work + 1));
     hipLaunchKernelGGL(k_coarse_final, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, flags, qnorm2, ix->maxn2,
-                       eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2);
+                       eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2, qerr2, measured);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1547,7 +1562,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
     hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, gthr,
                        qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
                        ix->cand_n);
-    if ((rc = launch_final_select(ix, nq, k, kSplitEps, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
+    if ((rc = launch_final_select(ix, nq, k, kSplitEps, nullptr, 0, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
                                   flag_list, D_dev, I_dev, nullptr, nullptr, 0, st)) != CSS_OK)
         return rc;
     return launch_fixup(ix, qpad, nq, k, gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
@@ -1598,6 +1613,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     const float eps_rel = sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f;
+    // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B
+    const int measured = env.eps_measured ? 1 : 0;
+    const float* qerr2 = sweep ? nullptr : ix->qerr2 + q0;
     const int l2 = ix->metric == CSS_METRIC_L2 ? 1 : 0;
     const float* xn2 = l2 ? ix->xnorm2 : nullptr;  // L2: coarse score = 2 x.q - ||x||^2
     int rc;
@@ -1623,7 +1641,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         // slots beyond the flagged count are scanned with a +inf threshold; their rows must still be finite numbers
         if (ix->qh2_cap != qh2_before) CSS_HIP_TRY(hipMemsetAsync(ix->qh2, 0, ix->qh2_cap * sizeof(unsigned short), st));
         if ((rc = grow(&ix->thr2, &ix->thr2_cap, (size_t)f2)) != CSS_OK) return rc;
-        if ((rc = grow(&ix->cand_n2, &ix->cand_n2_cap, (size_t)f2)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->cand_n2, &ix->cand_n2_cap, (size_t)f2 * CZ_NS)) != CSS_OK) return rc;
         if ((rc = grow(&ix->cand_s2, &ix->cand_s2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
         if ((rc = grow(&ix->cand_i2, &ix->cand_i2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
         if ((rc = grow(&ix->flagB, &ix->flagB_cap, (size_t)nq_pad + 1)) != CSS_OK) return rc;
@@ -1725,13 +1743,13 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
         ++stage_idx;
         if (s == 1) {
-            if ((rc = launch_final_select(ix, nq, k, eps_rel, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
+            if ((rc = launch_final_select(ix, nq, k, eps_rel, qerr2, measured, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
                                           I_dev, pass2 ? ix->thr2 : nullptr, pass2 ? ix->qh2 : nullptr, f2, st)) != CSS_OK)
                 return rc;
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
-                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, 0, ix->gthr + q0, ix->fix_s,
+                           ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, 0, ix->gthr + q0, qerr2, measured, ix->fix_s,
                            ix->fix_i, ix->fix_lock);
         CSS_LAUNCH_CHECK();
     }
@@ -1749,7 +1767,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
                                (const int*)nflag);
         }
         hipLaunchKernelGGL(k_rescore_parts<true>, dim3(kRescoreGrid), dim3(256), 0, st, ix->cand_s2, ix->cand_i2, ix->cand_n2,
-                           CZ_CAP2, f2, nflag, flag_list, ix->thr2, l2, qpad, ix->xb, ix->dpad);
+                           CZ_CAP2, f2, nflag, flag_list, ix->thr2, l2, qpad, ix->xb, ix->dpad, (const int*)nullptr, (const int*)nullptr);
         hipLaunchKernelGGL(k_coarse_select2<CZ_CAP2>, dim3(f2), dim3(256), 0, st, ix->cand_s2, ix->cand_i2, ix->cand_n2, nflag,
                            flag_list, f2, nflagB, flag_listB, l2, k, ix->id_base, D_dev, I_dev);
         CSS_LAUNCH_CHECK();
@@ -1927,13 +1945,14 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(st, ix->ingest_ev, 0));
     if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 256) * ix->dpad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->qerr2, &ix->qerr2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     // query prep: same row kernel as ingest (normalise, zero pad, squared norm)
     {
         const int64_t blocks = (nq + 3) / 4;
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, q_dev, ix->qpad,
                            ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll, (unsigned short*)nullptr,
-                           (int*)nullptr);
+                           (int*)nullptr, ix->qerr2);
         CSS_LAUNCH_CHECK();
     }
     if (ix->ntotal == 0) {
@@ -2029,8 +2048,8 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
         return css::hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
     }
     e = hipEventCreateWithFlags(&ix->ingest_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, 2 * sizeof(int));
     // (null-stream memset vs the non-blocking streams every later launch uses: order it here, once)
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -2049,10 +2068,10 @@ int css_index_free(css_index* ix) {
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
-    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->gthr, ix->qsplit,
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
-                    ix->qh2, ix->thr2, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};
+                    ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
@@ -2071,7 +2090,7 @@ int css_index_reset(css_index* ix) {
     DeviceGuard g(ix->device);
     if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
     if (ix->ws_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ws_ev, 0));   // a search enqueued on another stream still reads maxn2
-    CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, sizeof(int), ix->stream));
+    CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, 2 * sizeof(int), ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
 }

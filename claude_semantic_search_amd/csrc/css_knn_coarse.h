@@ -64,6 +64,13 @@ __global__ __launch_bounds__(256) void k_rows_to_bf16_x8(const float* __restrict
     }
 }
 
+// Band rescoring (k_rescore_parts): a band is split over at most CZ_PARTS blocks
+constexpr int CZ_PARTS = 16;
+// Spacing of the per-query candidate counters, in ints.  1 = packed: a 128-B line apart (32) was tried against the
+// returning device-scope atomics of the scan stages piling up on a few memory channels and measured no gain -- the
+// cost was in the hit loop of the tile epilogue, not in the atomics.
+constexpr int CZ_NS = 1;
+
 // thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
 // the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
 // flagged query claims take part in that scan with thr2 = +inf, i.e. without ever appending
@@ -77,12 +84,12 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
     }
     if (i < npace) pace[i] = 0;
     if (i < f2max) {
-        cand_n2[i] = 0;
+        cand_n2[(size_t)i * CZ_NS] = 0;
         thr2[i] = INFINITY;
     }
     if (i >= nq_pad) return;
     thr[i] = i < nq ? -INFINITY : INFINITY;
-    cand_n[i] = i < nq ? n0rows : 0;   // stage 0 writes its rows to fixed slots
+    cand_n[(size_t)(i) * CZ_NS] = i < nq ? n0rows : 0;   // stage 0 writes its rows to fixed slots
     flags[i] = 0;
 }
 
@@ -117,7 +124,7 @@ __device__ __forceinline__ unsigned cz_wave_or(unsigned v) {
             const unsigned fa_ = wl_base + (unsigned)i_ * 4u;                                                          \
             asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:%4\n\tds_read_b32 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)" \
                          : "=&v"(fs_), "=&v"(fr_), "=&v"(fq_) : "v"(fa_), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
-            const int slot_ = atomicAdd(&cand_n[fq_], 1);                                                              \
+            const int slot_ = atomicAdd(&cand_n[(size_t)(fq_) * CZ_NS], 1);                                                              \
             if (slot_ < KCAP) {                                                                                      \
                 cand_s[(size_t)fq_ * KCAP + slot_] = fs_;                                                            \
                 cand_i[(size_t)fq_ * KCAP + slot_] = fr_;                                                            \
@@ -176,12 +183,14 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
                     const float thr_q = sthr[wr * 128 + CZ_QOFF(m)];                                                   \
-                    bool any = false;                                                                                  \
+                    float mx_ = acc[m][0][0];   /* (v_max3_f32 chain: 8 instructions for the 16 scores of a lane) */   \
 _Pragma("unroll")                                                                                                      \
-                    for (int n = 0; n < TN; ++n)                                                                       \
-_Pragma("unroll")                                                                                                      \
-                        for (int r = 0; r < NR; ++r) any |= acc[m][n][r] >= thr_q;                                     \
-                    anym |= __ballot(any) != 0ull ? 1u << m : 0u;                                                      \
+                    for (int e = 1; e < TN * NR; e += 2) {                                                             \
+                        const float a_ = acc[m][e / NR][e % NR];                                                       \
+                        const float b_ = e + 1 < TN * NR ? acc[m][(e + 1) / NR][(e + 1) % NR] : a_;                    \
+                        mx_ = fmaxf(fmaxf(mx_, a_), b_);                                                               \
+                    }                                                                                                  \
+                    anym |= __ballot(mx_ >= thr_q) != 0ull ? 1u << m : 0u;                                             \
                 }                                                                                                      \
                 if (anym != 0u && !(dbg & 2)) {   /* dbg bit1 (timing experiments): votes only, no appends */           \
                     const bool edge = row0 + 64 > ntotal || mask != nullptr;   /* wave uniform */                      \
@@ -189,11 +198,13 @@ _Pragma("unroll")                                                               
                         /* k_scan_coarse8 (16x16 tiles: TM = 8, TN = 4, NR = 4).  The 8 waves of a block and the blocks     \
                            that share its row tiles move in lockstep, so a tile costs what its SLOWEST wave spends here:    \
                            the work per hit has to be small, not only the work per tile.  A query tile m with a hit builds   \
-                           each lane's 16-bit mask, ORs it over the wave, and a run-time loop visits only the score           \
-                           positions that hold a hit somewhere in the wave (one or two); the score comes out of the           \
-                           accumulator registers through a 16-way switch.  Hits go to this wave's LDS list (slot = wave       \
-                           count + rank of the lane among the hits of the position), which is written to the candidate        \
-                           buffers when it is nearly full and at the end of the kernel (CZ_FLUSH): no atomic round trip in    \
+                           each lane's 16-bit mask and every lane walks its OWN hits (a per-lane bit picks the score out   \
+                           of the 16 accumulator registers through a select tree), so a pass of the loop takes one hit     \
+                           from every lane that has one: the loop runs max-hits-per-lane times (1..3), not once per score  \
+                           position with a hit somewhere in the wave (~10 of 16 in the early stages, whose thresholds are  \
+                           loose: 65 us of an 87 us stage at 1.25 M rows).  Hits go to this wave's LDS list (slot = wave   \
+                           count + rank of the lane among the pass's hits), which is written to the candidate              \
+                           buffers when it is nearly full and at the end of the kernel (CZ_FLUSH): no atomic round trip in \
                            the tile loop. */                                                                                  \
 _Pragma("unroll")                                                                                                      \
                         for (int m = 0; m < TM; ++m) {                                                                 \
@@ -204,44 +215,34 @@ _Pragma("unroll")                                                               
                             for (int n = 0; n < TN; ++n)                                                               \
 _Pragma("unroll")                                                                                                      \
                                 for (int r = 0; r < NR; ++r) h |= (acc[m][n][r] >= thr_q ? 1u : 0u) << (n * NR + r);   \
-                            unsigned ho = cz_wave_or(h);                                                               \
                             const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + MS * m + lq);                     \
 _Pragma("nounroll")                                                                                                    \
-                            while (ho != 0u) {                                                                         \
-                                const int bit = __builtin_ctz(ho);                                                     \
-                                ho &= ho - 1u;                                                                         \
-                                float v_;                                                                              \
-                                switch (bit) {                                                                         \
-                                    default: v_ = acc[m][0][0]; break;                                                 \
-                                    case 1: v_ = acc[m][0][1]; break;                                                  \
-                                    case 2: v_ = acc[m][0][2]; break;                                                  \
-                                    case 3: v_ = acc[m][0][3]; break;                                                  \
-                                    case 4: v_ = acc[m][1][0]; break;                                                  \
-                                    case 5: v_ = acc[m][1][1]; break;                                                  \
-                                    case 6: v_ = acc[m][1][2]; break;                                                  \
-                                    case 7: v_ = acc[m][1][3]; break;                                                  \
-                                    case 8: v_ = acc[m][2][0]; break;                                                  \
-                                    case 9: v_ = acc[m][2][1]; break;                                                  \
-                                    case 10: v_ = acc[m][2][2]; break;                                                 \
-                                    case 11: v_ = acc[m][2][3]; break;                                                 \
-                                    case 12: v_ = acc[m][3][0]; break;                                                 \
-                                    case 13: v_ = acc[m][3][1]; break;                                                 \
-                                    case 14: v_ = acc[m][3][2]; break;                                                 \
-                                    case 15: v_ = acc[m][3][3]; break;                                                 \
-                                }                                                                                      \
-                                const int64_t row = row0 + 16 * (bit >> 2) + 4 * lg + (bit & 3);                       \
-                                bool hit = (h >> bit) & 1u;                                                            \
-                                if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);                          \
-                                const unsigned long long b = __ballot(hit);                                            \
-                                if (b == 0ull) continue;                                                               \
+                            while (true) {                                                                             \
+                                const bool has = h != 0u;                                                              \
+                                if (__ballot(has) == 0ull) break;                                                      \
                                 if (wcount + 64 > CZ_WCAP) {                                                           \
                                     CZ_FLUSH();                                                                        \
                                 }                                                                                      \
+                                const int bit = has ? __builtin_ctz(h) : 0;                                            \
+                                h &= h - 1u;                                                                           \
+                                /* acc[m][bit >> 2][bit & 3] of a per-lane bit: a 4-level select tree (15 v_cndmask) */\
+                                const bool s0_ = bit & 1, s1_ = bit & 2, s2_ = bit & 4, s3_ = bit & 8;                 \
+                                const float t0_ = s0_ ? acc[m][0][1] : acc[m][0][0], t1_ = s0_ ? acc[m][0][3] : acc[m][0][2];\
+                                const float t2_ = s0_ ? acc[m][1][1] : acc[m][1][0], t3_ = s0_ ? acc[m][1][3] : acc[m][1][2];\
+                                const float t4_ = s0_ ? acc[m][2][1] : acc[m][2][0], t5_ = s0_ ? acc[m][2][3] : acc[m][2][2];\
+                                const float t6_ = s0_ ? acc[m][3][1] : acc[m][3][0], t7_ = s0_ ? acc[m][3][3] : acc[m][3][2];\
+                                const float u0_ = s1_ ? t1_ : t0_, u1_ = s1_ ? t3_ : t2_, u2_ = s1_ ? t5_ : t4_, u3_ = s1_ ? t7_ : t6_;\
+                                const float w0_ = s2_ ? u1_ : u0_, w1_ = s2_ ? u3_ : u2_;                              \
+                                const float v_ = s3_ ? w1_ : w0_;                                                      \
+                                const int64_t row = row0 + 16 * (bit >> 2) + 4 * lg + (bit & 3);                       \
+                                bool hit = has;                                                                        \
+                                if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);                          \
+                                const unsigned long long b = __ballot(hit);                                            \
                                 if (hit) {                                                                             \
-                                    const unsigned sl = (unsigned)wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u)); \
+                                    const unsigned sl = (unsigned)wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));\
                                     const unsigned ad = wl_base + sl * 4u;                                             \
-                                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5" \
-                                                 : : "v"(ad), "v"(v_), "v"((unsigned)row), "v"(qv), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
+                                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"\
+                                                 : : "v"(ad), "v"(v_), "v"((unsigned)row), "v"(qv), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory");\
                                 }                                                                                      \
                                 wcount += __popcll(b);                                                                 \
                             }                                                                                          \
@@ -269,7 +270,7 @@ _Pragma("unroll")                                                               
                         if (h != 0u) {                                                                                 \
                             /* one returning atomic per lane and query tile reserves the slots of all its hits */      \
                             const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + CZ_QOFF(m));                      \
-                            int slot = atomicAdd(&cand_n[qv], __popc(h));                                              \
+                            int slot = atomicAdd(&cand_n[(size_t)(qv) * CZ_NS], __popc(h));                                              \
                             const size_t qb = (size_t)qv * KCAP;                                                     \
 _Pragma("unroll")                                                                                                      \
                             for (int n = 0; n < TN; ++n)                                                               \
@@ -923,14 +924,14 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
                     cand_i[o + 4] = okB ? (uint32_t)rowB : kInvalidRow;
                 } else {
                     if (ma >= my_thr && okA) {
-                        const int slot = atomicAdd(&cand_n[sub], 1);
+                        const int slot = atomicAdd(&cand_n[(size_t)(sub) * CZ_NS], 1);
                         if (slot < CZ_CAP) {
                             cand_s[(size_t)sub * CZ_CAP + slot] = ma;
                             cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowA;
                         }
                     }
                     if (mb >= my_thr && okB) {
-                        const int slot = atomicAdd(&cand_n[sub], 1);
+                        const int slot = atomicAdd(&cand_n[(size_t)(sub) * CZ_NS], 1);
                         if (slot < CZ_CAP) {
                             cand_s[(size_t)sub * CZ_CAP + slot] = mb;
                             cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowB;
@@ -987,27 +988,33 @@ __device__ __forceinline__ void cz_rescore_rows(float* s, const uint32_t* id, in
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[r][e] = 0.f;
-        for (int j = lane; j < nj; j += 64) {
-            const float4 y = qv[j];
-            float4 x[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = xv[r][j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (l2) {
-                    const float dx = x[r].x - y.x, dy = x[r].y - y.y, dz = x[r].z - y.z, dw = x[r].w - y.w;
-                    a[r][0] = fmaf(dx, dx, a[r][0]);
-                    a[r][1] = fmaf(dy, dy, a[r][1]);
-                    a[r][2] = fmaf(dz, dz, a[r][2]);
-                    a[r][3] = fmaf(dw, dw, a[r][3]);
-                } else {
-                    a[r][0] = fmaf(x[r].x, y.x, a[r][0]);
-                    a[r][1] = fmaf(x[r].y, y.y, a[r][1]);
-                    a[r][2] = fmaf(x[r].z, y.z, a[r][2]);
-                    a[r][3] = fmaf(x[r].w, y.w, a[r][3]);
-                }
-            }
+#define CZ_RESCORE_STEP(J_)                                                                        \
+        {                                                                                              \
+            const float4 y = qv[J_];                                                                   \
+            float4 x[4];                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) x[r] = xv[r][J_];                            \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                if (l2) {                                                                              \
+                    const float dx = x[r].x - y.x, dy = x[r].y - y.y, dz = x[r].z - y.z, dw = x[r].w - y.w; \
+                    a[r][0] = fmaf(dx, dx, a[r][0]);                                                   \
+                    a[r][1] = fmaf(dy, dy, a[r][1]);                                                   \
+                    a[r][2] = fmaf(dz, dz, a[r][2]);                                                   \
+                    a[r][3] = fmaf(dw, dw, a[r][3]);                                                   \
+                } else {                                                                               \
+                    a[r][0] = fmaf(x[r].x, y.x, a[r][0]);                                              \
+                    a[r][1] = fmaf(x[r].y, y.y, a[r][1]);                                              \
+                    a[r][2] = fmaf(x[r].z, y.z, a[r][2]);                                              \
+                    a[r][3] = fmaf(x[r].w, y.w, a[r][3]);                                              \
+                }                                                                                      \
+            }                                                                                          \
         }
+        if (nj == 192) {   // dim 768 (the reference's model): fixed trip count, all 12 row loads of a pass in flight together
+#pragma unroll
+            for (int it = 0; it < 3; ++it) CZ_RESCORE_STEP(lane + 64 * it)
+        } else {
+            for (int j = lane; j < nj; j += 64) CZ_RESCORE_STEP(j)
+        }
+#undef CZ_RESCORE_STEP
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float e = wave_allsum((a[r][0] + a[r][1]) + (a[r][2] + a[r][3]));
@@ -1016,13 +1023,31 @@ __device__ __forceinline__ void cz_rescore_rows(float* s, const uint32_t* id, in
     }
 }
 
-__device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int l2) {
-    // IP: |c - x.q| <= eps_rel ||q|| max||x||.  L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2):
-    // twice that, plus the fp32 cancellation of the expanded form
-    float eps = eps_rel * sqrtf(qn2) * sqrtf(mx2) + 1e-30f;
+// Error bound of a coarse score c of row x for query q.
+//   a priori   : |c - x.q| <= eps_rel ||q|| max||x|| (unit roundoff of the rounded operands, Cauchy-Schwarz).
+//   measured   : c - x.q = (x^ - x).q^ + x.(q^ - q) exactly (x^, q^ the bf16 operands), so
+//                |c - x.q| <= max||x^ - x|| (||q|| + ||q^ - q||) + max||x|| ||q^ - q||  +  2^-11 ||q|| max||x||
+//                (last term: fp32 accumulation, ~10 x its worst case at dim 768).  The error norms are what the
+//                conversions actually produced: max over the index rows (k_ingest_rows, second word of maxn2) and
+//                per query (qerr2; 0 for the sweep, whose queries stay fp32).  ex2 < 0: a priori bound only (the
+//                split-operand scan, whose operands are not the bf16 roundings).  Random rows: ~0.41 of a unit
+//                roundoff each, the band is ~2.3 x narrower than the a-priori one and holds ~3 x fewer rows.
+// L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2): twice that, plus the fp32 cancellation
+// of the expanded form.
+__device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int l2, float ex2, float qe2) {
+    const float qn = sqrtf(qn2), mx = sqrtf(mx2);
+    float eps = eps_rel * qn * mx;
+    if (ex2 >= 0.f) {
+        const float qe = sqrtf(qe2);
+        // (1.001: rounding of the fp32 sums behind the error norms, ~dim * 2^-24 relative)
+        eps = fminf(eps, 1.001f * (sqrtf(ex2) * (qn + qe) + mx * qe) + 0.00048828125f * qn * mx);
+    }
+    eps += 1e-30f;
     if (l2) eps = 2.f * eps + 9.5367431640625e-07f * (mx2 + qn2);
     return eps;
 }
+#define CZ_EPS_OF(Q_) cz_eps(eps_rel, qnorm2[Q_], __int_as_float(maxn2_bits[0]), l2,                      \
+                             measured ? __int_as_float(maxn2_bits[1]) : -1.f, (measured && qerr2) ? qerr2[Q_] : 0.f)
 
 // One block per query.  Between the stages of the cascade (FINAL = false): sort the candidate buffer, take the k-th
 // best coarse score Tc, publish thr = Tc - 2 eps and keep only the entries >= thr.  After the last stage (FINAL =
@@ -1033,7 +1058,8 @@ __device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int
 // A query whose band or buffer overflowed is FLAGGED: flags[q] = its slot in flag_list + 1.  Only the 512 best
 // buffered candidates of such a query are rescored: all that is wanted from them is a lower bound of the exact k-th
 // best score for the second pass, and any subset of rows gives one.
-constexpr int CZ_PARTS = 16;
+// Rows per part of a band of n rows split over at most CZ_PARTS blocks (a multiple of the 16 rows a block has in flight)
+__device__ __forceinline__ int cz_part_rows(int n) { return (((n + CZ_PARTS - 1) / CZ_PARTS) + 15) & ~15; }
 constexpr int CZ_FLAGGED_RESCORE = 512;
 // k-th largest of s[0 .. n) (n >= k) by a most-significant-digit radix selection over order-preserving 32-bit keys: four
 // passes of an 8-bit LDS histogram + one wave's suffix scan over the 256 bins.  The stage selects need the k-th best
@@ -1098,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
                                                        int* __restrict__ flag_list, const float* __restrict__ qnorm2,
                                                        const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
                                                        int closed_n, int* __restrict__ gthr,
+                                                       const float* __restrict__ qerr2, int measured,
                                                        float* __restrict__ fix_s, uint32_t* __restrict__ fix_i,
                                                        int* __restrict__ fix_lock) {
     __shared__ float s[CZ_CAP];
@@ -1106,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     __shared__ int sel[2];
     __shared__ int cnt;
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int n_raw = cand_n[q];
+    const int n_raw = cand_n[(size_t)(q) * CZ_NS];
     const bool overflow = n_raw > CZ_CAP;
     const int n = min(n_raw, CZ_CAP);
     for (int i = tid; i < n; i += 256) {
@@ -1116,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     if (tid == 0) cnt = 0;
     __syncthreads();
     const float Tc = n >= k ? cz_kth_largest(s, n, k, hist, sel, tid) : -INFINITY;
-    const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(*maxn2_bits), l2);
+    const float eps = CZ_EPS_OF(q);
     const float thr_new = Tc - 2.f * eps;  // -inf stays -inf
     bool bad = false;
     if constexpr (FINAL) {
@@ -1139,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     const int m = cnt;
     if constexpr (!FINAL) {
         if (tid == 0) {
-            cand_n[q] = m;
+            cand_n[(size_t)(q) * CZ_NS] = m;
             thr[q] = thr_new;
             if (overflow) flags[q] = 1;
         }
@@ -1177,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
             R = cnt;
         }
         if (tid == 0) {
-            cand_n[q] = R;
+            cand_n[(size_t)(q) * CZ_NS] = R;
             int fl = 0;
             if (bad) {
                 gthr[q] = f2key(-INFINITY);
@@ -1191,6 +1218,43 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
     }
 }
 
+// Work list of the band rescoring: the (query, part) items that exist, in query order -- one block, an exclusive
+// scan over the per-query part counts.  (Built inside k_coarse_select<true> with returning atomics it cost that
+// kernel 11-25 us; launching all CZ_PARTS parts of every query cost the rescoring 65 us of block dispatch.)
+__global__ __launch_bounds__(1024) void k_rescore_plan(const int* __restrict__ cand_n, int nq, int* __restrict__ work_n,
+                                                       int* __restrict__ work) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024) {
+        const int q = q0 + tid;
+        int np = 0;
+        if (q < nq) {
+            const int n = min(cand_n[(size_t)q * CZ_NS], CZ_CAP);
+            const int per = cz_part_rows(n);
+            np = (n + per - 1) / per;
+        }
+        int incl = np;   // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int pre = base;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        const int pos = pre + incl - np;
+        for (int p = 0; p < np; ++p) work[pos + p] = q * CZ_PARTS + p;
+        __syncthreads();
+        if (tid == 1023) base = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *work_n = base;
+}
+
 // Exact scores for candidate buffers, CZ_PARTS work items per buffer, grid-stride over the items.
 //   PASS2 = false: buffer of query q = slot (cap CZ_CAP, cand_n[q] band rows left by k_coarse_select<true>);
 //   PASS2 = true:  buffer of slot b < min(*nflag, f2max) belongs to query flag_list[b] (cap entries per slot);
@@ -1200,14 +1264,19 @@ __global__ __launch_bounds__(256) void k_rescore_parts(float* __restrict__ cand_
                                                        const int* __restrict__ cand_n, int cap, int nslots_arg,
                                                        const int* __restrict__ nflag, const int* __restrict__ flag_list,
                                                        const float* __restrict__ thr2, int l2,
-                                                       const float* __restrict__ qpad, const float* __restrict__ xb, int dpad) {
+                                                       const float* __restrict__ qpad, const float* __restrict__ xb, int dpad,
+                                                       const int* __restrict__ work_n, const int* __restrict__ work) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nslots = PASS2 ? min(*nflag, nslots_arg) : nslots_arg;
-    for (int item = blockIdx.x; item < nslots * CZ_PARTS; item += gridDim.x) {
+    // work != null: the list of (slot, part) items that exist, left by k_rescore_plan (a batch of 1000 queries
+    // has ~2 live parts per query: launching all 16 was 16000 blocks and 88 us, most of it block dispatch)
+    const int nitems = work ? *work_n : nslots * CZ_PARTS;
+    for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+        const int item = work ? work[w] : w;
         const int slot = item / CZ_PARTS, part = item % CZ_PARTS;
-        const int n = cand_n[slot];
+        const int n = cand_n[(size_t)(slot) * CZ_NS];
         if (n > cap) continue;
-        const int per = (((n + CZ_PARTS - 1) / CZ_PARTS) + 15) & ~15;
+        const int per = cz_part_rows(n);
         const int lo = part * per, hi = min(n, lo + per);
         if (lo >= hi) continue;
         const int q = PASS2 ? flag_list[slot] : slot;
@@ -1228,11 +1297,12 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
                                                       const float* __restrict__ qnorm2, const int* __restrict__ maxn2_bits,
                                                       float eps_rel, int l2, int k, const float* __restrict__ qpad, int dpad,
                                                       int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
-                                                      float* __restrict__ thr2, unsigned short* __restrict__ qh2, int f2max) {
+                                                      float* __restrict__ thr2, unsigned short* __restrict__ qh2, int f2max,
+                                                      const float* __restrict__ qerr2, int measured) {
     __shared__ float s[CZ_CAP];
     __shared__ uint32_t id[CZ_CAP];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int R = min(cand_n[q], CZ_CAP);
+    const int R = min(cand_n[(size_t)(q) * CZ_NS], CZ_CAP);
     int P = 2;
     while (P < R) P <<= 1;
     for (int i = tid; i < P; i += 256) {
@@ -1250,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     if (fslot >= 0 && thr2 != nullptr && fslot < f2max) {
         // second coarse pass: coarse scores are x.q (IP) or 2 x.q - ||x||^2 = -(||x - q||^2) + ||q||^2 (L2)
         if (tid == 0) {
-            const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(*maxn2_bits), l2);
+            const float eps = CZ_EPS_OF(q);
             thr2[fslot] = (R >= k && id[k - 1] != kInvalidRow) ? s[k - 1] + (l2 ? qnorm2[q] : 0.f) - eps : -INFINITY;
         }
         for (int i = tid; i < dpad; i += 256)
@@ -1278,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_coarse_select2(const float* __restrict_
         for (int i = f2max + tid; i < nf; i += 256) flag_listB[atomicAdd(nflagB, 1)] = flag_list[i];
     if (b >= min(nf, f2max)) return;
     const int q = flag_list[b];
-    const int n = cand_n[b];
+    const int n = cand_n[(size_t)(b) * CZ_NS];
     if (n > CAP2) {
         if (tid == 0) flag_listB[atomicAdd(nflagB, 1)] = q;
         return;

@@ -1265,7 +1265,7 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
-    int growth = 4;       // CSS_KNN_GROWTH=8: growth factor of the nested row sample (batched MFMA cascade)
+    int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
@@ -1279,7 +1279,10 @@ const KnnEnv& knn_env() {
         KnnEnv e;
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
         if (const char* m = getenv("CSS_KNN_EPS")) e.eps_measured = strcmp(m, "apriori") != 0;
-        if (const char* m = getenv("CSS_KNN_GROWTH")) e.growth = atoi(m) == 8 ? 8 : 4;
+        if (const char* m = getenv("CSS_KNN_GROWTH")) {
+            const int v = atoi(m);
+            e.growth = (v == 4 || v == 8 || v == 16) ? v : 0;
+        }
         if (const char* m = getenv("CSS_KNN_GROWTH_SWEEP")) {
             const int v = atoi(m);
             e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 4;
@@ -1653,14 +1656,16 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // cascade schedule: a nested, uniformly strided sample of row tiles.  Stage 0 reads every s-th tile (at most 15
     // tiles: it keeps every score, 3840 of the 4096 slots), every later stage the tiles at a stride `ratio` times
     // smaller that were not read before; the last stage has stride 1.
-    // Growth factor g: every stage reads g-1 times the tiles read before it.  Batches (MFMA scan): g = 4 -- the last
-    // stage is 3/4 of the rows and appends ~3k + band candidates per query; g = 8 measured 2 % slower (more appends in
-    // the lockstep epilogue of the main stage).  1..4 queries (sweep): also g = 4.  Fewer, larger stages do not help
+    // Growth factor g: every stage reads g-1 times the tiles read before it.  Batches (MFMA scan): g = 8 for k <= 32
+    // (4 stages at 1.25 M rows instead of 6; the last stage is 7/8 of the rows and appends ~7k + band candidates per
+    // query, cheap since the tile epilogue walks hits per lane: 10 M x 1000, k = 10: 12.25 ms vs 12.47 at g = 4, 100 k
+    // rows 0.32 vs 0.34 ms; g = 16: 12.4 ms), g = 4 above (k = 100: 13.55 vs 13.79 ms; k = 32..64 equal).  Round 2's
+    // epilogue made g = 8 2 % slower.  1..4 queries (sweep): g = 4.  Fewer, larger stages do not help
     // there -- measured at 10 M rows, k = 10: g = 4 / 8 / 16 (7 / 5 / 4 stages) all take 2.71-2.72 ms, the call is the
     // 15.36 GB of shadow rows at the sweep's bandwidth plus ~0.25 ms -- and with k = 100 (the reference's call shape)
     // g = 16 overflows the 4096-slot buffers (~k g candidates per stage) and lands in the exact fix-up: 10 ms.
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
-    const int g = sweep ? env.growth_sweep : env.growth;
+    const int g = sweep ? env.growth_sweep : (env.growth ? env.growth : (k <= 32 ? 8 : 4));
     struct Stage {
         int64_t stride;
         int ratio;   // stride of the previous stage / this stride (stage 0: unused)

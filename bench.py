@@ -41,7 +41,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-CASCADE_GROWTH = 8 if os.environ.get("CSS_KNN_GROWTH") == "8" else 4   # growth factor of the coarse cascade (css_index.hip)
+def cascade_growth(k: int) -> int:
+    """Growth factor of the batched coarse cascade (css_index.hip, launch_scan_coarse): CSS_KNN_GROWTH, else by k."""
+    env = os.environ.get("CSS_KNN_GROWTH", "")
+    if env in ("4", "8", "16"):
+        return int(env)
+    return 8 if k <= 32 else 4
+
+
 SWEEP_GROWTH = int(os.environ.get("CSS_KNN_GROWTH_SWEEP", "4"))         # ... of the 1..4-query sweep cascade
 if SWEEP_GROWTH not in (4, 8, 16):
     SWEEP_GROWTH = 4
@@ -643,17 +650,18 @@ def _main(argv, platform_factory):
         avg_s = ms / n / 1e3
         sweep_bytes = shard * args.dim * 4          # algorithmic bytes of one fp32 sweep of this rank's shard
         if dom == "knn_scan_coarse_main":
-            # last stage of the cascade (k_scan_coarse<false,true,..>): the row tiles t with t % g != 0 (g = 4), i.e.
-            # 3/4 of the shard, one bf16 MFMA product per (row, query, k); see css_knn_coarse.h
+            # last stage of the cascade (k_scan_coarse8<false,true,..>): the row tiles t with t % g != 0 (g = 8 at
+            # k <= 32), i.e. 7/8 of the shard, one bf16 MFMA product per (row, query, k); see css_knn_coarse.h
             ntiles = -(-shard // 256)
-            main_tiles = (ntiles - 1) - (ntiles - 1) // CASCADE_GROWTH
+            g_ = cascade_growth(args.k)
+            main_tiles = (ntiles - 1) - (ntiles - 1) // g_
             main_rows = min(main_tiles * 256, shard)
             flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
             sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
             roofline = {"bound": "mfma", "kernel": "k_scan_coarse8<false,true> (main stage of the cascade)",
                         "achieved": flops / avg_s / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None,
-                        "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows,
+                        "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows, "cascade_growth": g_,
                         "hbm_GBps": sweep_bytes / avg_s / 1e9,
                         "arithmetic": "bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_16x16x32_bf16; "
                                       "candidates rescored in fp32",

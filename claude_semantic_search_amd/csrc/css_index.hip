@@ -468,6 +468,13 @@ __global__ void k_fill_pad(float* __restrict__ D, int64_t* __restrict__ I, int64
 // when something passes is the tile spilled to an LDS scratch and inserted into
 // the wave-owned sorted lists.  Thresholds are also exchanged grid-wide (gthr).
 constexpr int MF_BM = 128, MF_BN = 128, MF_BK = 32;
+#ifndef CSS_MF_LAG
+#define CSS_MF_LAG 12
+#endif
+#ifndef CSS_MF_POLL
+#define CSS_MF_POLL 8   // (a power of two)
+#endif
+constexpr int MF_LAG = CSS_MF_LAG;   // K-steps a block may run ahead of its slowest sibling (k_scan_mfma pacing)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));  // plain clang vector: stays in VGPRs
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
                                                       int dpad, int k, int nstrips, int nqtiles,
                                                       int64_t tiles_per_strip, int* __restrict__ gthr,
                                                       float* __restrict__ part_s, uint32_t* __restrict__ part_i,
-                                                      const uint32_t* __restrict__ mask) {
+                                                      const uint32_t* __restrict__ mask, int* __restrict__ pace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                 // [2][128][32]
     float* Bs = As + 2 * MF_BM * MF_BK;                         // [2][128][32]
@@ -555,6 +562,23 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
     int64_t rt = t_begin;  // row tile / K-step of the tile being computed
     int kt = 0;
     for (int64_t it = 0; it < n_it; ++it) {
+        // Sibling pacing: the nqtiles blocks of a strip sit on one XCD and read the same rows.  Every CSS_MF_POLL-th
+        // K-step a block publishes its step count and looks at its siblings'; it does not run more than MF_LAG steps
+        // ahead of the slowest, so a K-step of rows (16 KB) is still in that XCD's L2 when the others ask for it.
+        // Unpaced, the siblings drift apart with their insert work and each fetches the strip from HBM again.
+        // Measured at 10 M rows x 256 queries (rocprofv3 --pmc FETCH_SIZE, 30.72 GB algorithmic): unpaced 52.0 GB
+        // (1.69 x) in 49.0 ms; poll 8 / lag 12: 34.0 GB (1.11 x) in 50.6 ms; poll 4 / lag 8: 33.2 GB, 51.9 ms; poll
+        // 16 / lag 16: 43.0 GB, 49.8 ms.  The kernel is bound by the fp32 MFMA pipe, not by HBM, so the saved traffic
+        // buys no time here (it frees HBM for whatever else runs on the chip); CSS_KNN_PACE=0 turns it off.
+        // The look is issued here and used after the MFMAs of the step; the spin is bounded, so a sibling that is
+        // not resident only costs a wait.
+        int sib_lo = 1 << 30;
+        const bool pace_now = pace != nullptr && tid == 0 && (it & (CSS_MF_POLL - 1)) == 0;
+        if (pace_now) {
+            __hip_atomic_store(pace + (size_t)strip * nqtiles + qtile, (int)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < nqtiles; ++j)
+                sib_lo = min(sib_lo, __hip_atomic_load(pace + (size_t)strip * nqtiles + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
         if (it + 1 < n_it) {
             const int64_t nrt = kt + 1 < KT ? rt : rt + 1;
             const int nkt = kt + 1 < KT ? kt + 1 : 0;
@@ -632,6 +656,16 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
         }
+        if (pace_now && sib_lo + MF_LAG < (int)it) {
+            int spin = 0;
+            for (; spin < 2048 && sib_lo + MF_LAG < (int)it; ++spin) {
+                __builtin_amdgcn_s_sleep(4);
+                sib_lo = 1 << 30;
+                for (int j = 0; j < nqtiles; ++j)
+                    sib_lo = min(sib_lo, __hip_atomic_load(pace + (size_t)strip * nqtiles + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            if (spin == 2048) pace = nullptr;   // a sibling is not running: stop waiting for it (thread 0's copy is the one used)
+        }
         if (it + 1 < n_it) {
             MF_SSTORE(cur ^ 1)
         }
@@ -644,6 +678,9 @@ __global__ __launch_bounds__(256, 1) void k_scan_mfma(const float* __restrict__ 
     }
 #undef MF_GLOAD
 #undef MF_SSTORE
+    // (a block that is done must not hold its siblings back)
+    if (pace != nullptr && tid == 0)
+        __hip_atomic_store(pace + (size_t)strip * nqtiles + qtile, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // part layout: [q][strip][k]
     for (int i = tid; i < MF_BN * k; i += 256) {
         const int j = i / k, p = i - j * k;
@@ -1465,10 +1502,17 @@ int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_
     CSS_LAUNCH_CHECK();
     auto kern = k_scan_mfma<METRIC>;
     if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    // sibling pacing (see the kernel) where a strip has siblings; the counters share the cascade's pacing words
+    int* pace = nullptr;
+    if (knn_env().pacing && nqtiles > 1 && nstrips * nqtiles <= ix->num_cus) {   // (all blocks resident: one per CU)
+        if ((rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)nstrips * nqtiles)) != CSS_OK) return rc;
+        pace = ix->cpace;
+        CSS_HIP_TRY(hipMemsetAsync(pace, 0, (size_t)nstrips * nqtiles * sizeof(int), st));
+    }
     {
         ProfScope ps("knn_scan_mfma", st);
         hipLaunchKernelGGL(kern, dim3(nstrips * nqtiles), dim3(256), lds, st, ix->xb, ix->xnorm2, ix->qpad, nq,
-                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask);
+                           ix->ntotal, ix->dpad, k, nstrips, nqtiles, tps, ix->gthr, ix->part_s, ix->part_i, ix->cur_mask, pace);
         CSS_LAUNCH_CHECK();
     }
     {

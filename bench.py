@@ -676,7 +676,7 @@ def _main(argv, platform_factory):
                         "launches": n, "avg_ms": ms / n}
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
         tr = None
-        for pref in ({"knn_scan_coarse_main": ("k_scan_coarse8<false, true", "k_scan_coarse<false, true")}.get(dom, ("k_scan_small",))):
+        for pref in ({"knn_scan_coarse_main": ("k_scan_coarse8<false, true, false, 4096>", "k_scan_coarse<false, true")}.get(dom, ("k_scan_small",))):
             tr = tr or pmc_traffic(pref, wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]

@@ -10,6 +10,11 @@
 //   v1  8-phase ping-pong: four 16-MFMA phases per K step, half-tile DMA slots three ahead with a counted
 //       vmcnt, two barriers per phase, the two wave rows staggered by one barrier so that one wave of every
 //       SIMD runs MFMAs while its partner reads fragments and issues DMA
+//   v3  (mask 8; v4 = mask 16 with sched_group_barrier hints) round 3 prototype: FOUR waves of 128 x 128 (one per SIMD,
+//       accumulators meant for AGPRs) on v0's loop -- a third less LDS read traffic per flop.  As written hipcc keeps
+//       part of the accumulators in VGPRs (48-66 spills) and does not interleave the fragment reads with the MFMAs:
+//       500 TFLOP/s against v1's 1095 on the FFN1 shape.  A contender only with inline-asm AGPR MFMAs and a
+//       hand-placed read schedule, as v1 needed.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -558,6 +563,153 @@ __global__ __launch_bounds__(512) void k_gemm_v1(const bf16_t* __restrict__ A, c
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
 }
 
+// ------------------------------------------------------------------------------------------------ v3
+// Four waves (one per SIMD), each a 128 x 128 output tile: 256 accumulator registers per lane (the unified 512-register
+// file of a single-wave SIMD), 16 fragment reads per 64 MFMAs instead of 12 per 32 -- 64 KB of LDS reads per 32-deep K
+// step and CU instead of 96 KB.  Loop of v0 (two 64-KiB stages, one barrier per K step); the reads of the next half
+// step are left to the compiler to place among the MFMAs of the current one.
+template <int SCHED>
+__global__ __launch_bounds__(256) void k_gemm_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                 const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
+                                                 int K, int dbg = 0) {
+    constexpr int NW = 4, WN = 2, TM = 8, TN = 8, BM = 256, BN = 256, RB = 128;
+    constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB, PPW = 16;
+    constexpr int E = 4 * TM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float sbias[BN];
+    constexpr int EPI_ROW = 272;
+    __shared__ __attribute__((aligned(16))) char sepi[NW][16 * EPI_ROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lq = lane & 15, lg = lane >> 4;
+    float4 bias_regs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
+    const int KT = K / 64;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    // pieces wave + 4 i: i < 8 rows of A, i >= 8 rows of W, 32 rows apart; the swizzle term is the same for every i
+    const char* srcA;
+    const char* srcB;
+    const size_t step32 = (size_t)32 * K * 2;
+    const int dst0 = wave * 1024;
+    auto set_src = [&](int tile_idx) {
+        const int tile = xfirst + jx + tile_idx * per_x;
+        const int r0 = (tile / ntn) * BM, c0 = (tile % ntn) * BN;
+        const int trow = wave * 8 + prow;
+        const int sw = (pchunk ^ ((trow >> 1) & 7)) << 4;
+        srcA = reinterpret_cast<const char*>(A + (size_t)(r0 + trow) * K) + sw;   // (rows beyond M: the buffer's slack rows)
+        srcB = reinterpret_cast<const char*>(W + (size_t)(c0 + trow) * K) + sw;
+    };
+#define V3_ISSUE(KT_, SLOT_)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + i * step32 + (size_t)(KT_) * RB), \
+                                         (__attribute__((address_space(3))) void*)(smem + (SLOT_) * STAGE + dst0 + i * 4096), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB + i * step32 + (size_t)(KT_) * RB), \
+                                         (__attribute__((address_space(3))) void*)(smem + (SLOT_) * STAGE + A_BYTES + dst0 + i * 4096), 16, 0, 0); \
+    }
+    // fragment (16 m + lq, k chunk 4 c + lg): 16 rows further = +2048 B, the other half step = XOR 64 (rows 16 apart share
+    // the swizzle term)
+    const int aoff = swz_byte(wr * 128 + lq, lg), boff = swz_byte(wc * 128 + lq, lg);
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+    int it_tile = 0, it_kt = 0, gi = 0;
+    set_src(0);
+    V3_ISSUE(0, 0)
+    gi = 1;
+    if (++it_kt == KT) {
+        it_kt = 0;
+        if (++it_tile < my_ntiles) set_src(it_tile);
+    }
+    int ct_tile = 0, kt = 0;
+    for (int g = 0; g < total; ++g) {
+        if (ct_tile > 0 && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0 && kt == 2) {
+            *reinterpret_cast<float4*>(&sbias[4 * lane]) = bias_regs;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && kt == 1) {
+            const int tile_b = xfirst + jx + ct_tile * per_x;
+            bias_regs = *reinterpret_cast<const float4*>(bias + (tile_b % ntn) * BN + 4 * lane);
+        }
+        if (gi < total) {
+            V3_ISSUE(it_kt, gi & 1)
+            ++gi;
+            if (++it_kt == KT) {
+                it_kt = 0;
+                if (++it_tile < my_ntiles) set_src(it_tile);
+            }
+        }
+        const char* Ab = smem + (g & 1) * STAGE;
+        const char* Bb = Ab + A_BYTES;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            v4f a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4f*>(Ab + (aoff ^ (c * 64)) + m * 2048);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4f*>(Bb + (boff ^ (c * 64)) + n * 2048);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = LAB_MFMA(__builtin_bit_cast(v8in, b[n]), __builtin_bit_cast(v8in, a[m]), acc[m][n], 0, 0, 0);
+            if (SCHED == 1) {   // 16 reads spread over the 64 MFMAs of the half step before
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+            }
+        }
+        if (++kt == KT) {
+            const int tile = xfirst + jx + ct_tile * per_x;
+            const int col0 = (tile % ntn) * BN + wc * 128;
+            float4 bv[TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bv[n] = *reinterpret_cast<const float4*>(&sbias[wc * 128 + 16 * n + 4 * lg]);
+            if (!(dbg & 1))
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                char* mine = sepi[wave];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(acc[m][n][0] + bv[n].x) | ((unsigned)f2bf(acc[m][n][1] + bv[n].y) << 16);
+                    pk.y = (unsigned)f2bf(acc[m][n][2] + bv[n].z) | ((unsigned)f2bf(acc[m][n][3] + bv[n].w) << 16);
+                    *reinterpret_cast<uint2*>(mine + lq * EPI_ROW + (16 * n + 4 * lg) * 2) = pk;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = 4 * t + (lane >> 4);
+                    const uint4 o = *reinterpret_cast<const uint4*>(mine + rr * EPI_ROW + (lane & 15) * 16);
+                    const size_t gidx = (size_t)((tile / ntn) * BM + wr * 128 + 16 * m + rr) * N + col0 + (lane & 15) * 8;
+                    *reinterpret_cast<uint4*>(Cout + gidx) = o;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            ++ct_tile;
+        }
+    }
+#undef V3_ISSUE
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static inline float bf2f_host(bf16_t h) {
     uint32_t u = (uint32_t)h << 16;
@@ -619,14 +771,18 @@ int main(int argc, char** argv) {
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v0<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&](int v) {
-        if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        if (v == 3) hipLaunchKernelGGL(k_gemm_v3<0>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        else if (v == 4) hipLaunchKernelGGL(k_gemm_v3<1>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        else if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 3>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else hipLaunchKernelGGL((k_gemm_v1<0, false, 0>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
     };
     // ---- correctness: sampled elements against an fp64 host reference
     std::vector<bf16_t> hC((size_t)M * N);
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 5; ++v) {
         if (!(mask & (1 << v))) continue;
         HIP_OK(hipMemset(dC, 0xFF, Mpad * N * 2));
         launch(v);
@@ -663,10 +819,10 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0));
     HIP_OK(hipEventCreate(&e1));
-    double best[3] = {1e30, 1e30, 1e30}, sum[3] = {0, 0, 0};
+    double best[5] = {1e30, 1e30, 1e30, 1e30, 1e30}, sum[5] = {0, 0, 0, 0, 0};
     const int rounds = 5;
     for (int r = 0; r < rounds; ++r)
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < 5; ++v) {
             if (!(mask & (1 << v))) continue;
             for (int i = 0; i < 3; ++i) launch(v);
             HIP_OK(hipEventRecord(e0, 0));
@@ -679,7 +835,7 @@ int main(int argc, char** argv) {
             if (ms < best[v]) best[v] = ms;
             sum[v] += ms;
         }
-    for (int v = 0; v < 3; ++v)
+    for (int v = 0; v < 5; ++v)
         if (mask & (1 << v))
             printf("v%d: best %.4f ms (%.0f TFLOP/s), mean %.4f ms (%.0f TFLOP/s)\n", v, best[v], 2.0 * M * N * K / best[v] / 1e9,
                    sum[v] / rounds, 2.0 * M * N * K / (sum[v] / rounds) / 1e9);

@@ -1034,13 +1034,16 @@ __device__ __forceinline__ void cz_rescore_rows(float* s, const uint32_t* id, in
 //                roundoff each, the band is ~2.3 x narrower than the a-priori one and holds ~3 x fewer rows.
 // L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2): twice that, plus the fp32 cancellation
 // of the expanded form.
+#ifndef CZ_EPS_TEST_SCALE
+#define CZ_EPS_TEST_SCALE 1.f   // (mutation builds: a band drawn too narrow must make tests/test_knn_gpu.py fail)
+#endif
 __device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int l2, float ex2, float qe2) {
     const float qn = sqrtf(qn2), mx = sqrtf(mx2);
     float eps = eps_rel * qn * mx;
     if (ex2 >= 0.f) {
         const float qe = sqrtf(qe2);
         // (1.001: rounding of the fp32 sums behind the error norms, ~dim * 2^-24 relative)
-        eps = fminf(eps, 1.001f * (sqrtf(ex2) * (qn + qe) + mx * qe) + 0.00048828125f * qn * mx);
+        eps = fminf(eps, CZ_EPS_TEST_SCALE * 1.001f * (sqrtf(ex2) * (qn + qe) + mx * qe) + 0.00048828125f * qn * mx);
     }
     eps += 1e-30f;
     if (l2) eps = 2.f * eps + 9.5367431640625e-07f * (mx2 + qn2);

@@ -272,6 +272,102 @@ def test_coarse_clustered_rows_dense_bands():
     _check_against_oracle(x, q, 10, True, "clustered")
 
 
+def _to_bf16_midpoints(a):
+    """Every element moved to the exact midpoint between two neighbouring bf16 values: round-to-nearest-even then
+    loses a full half ulp per element, the largest rounding error a bf16 copy can have."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((u & np.uint32(0xFFFF0000)) | np.uint32(0x8000)).view(np.float32)
+
+
+def test_coarse_measured_error_band_holds_for_worst_case_roundings():
+    # The candidate band is drawn from the rounding errors MEASURED at ingest and query preparation (cz_eps), not from
+    # the unit roundoff.  Worst case for that: operands on bf16 midpoints, a dense cluster whose exact scores differ by
+    # far less than the coarse error, and the badly rounding rows arriving in a LATER add than rows that round exactly.
+    rng = np.random.default_rng(7)
+    exact_rows = synth.rows(20000, 768, 51)
+    exact_rows /= np.linalg.norm(exact_rows, axis=1, keepdims=True)
+    exact_rows = (exact_rows.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)      # bf16-representable: error 0
+    cent = synth.rows(6, 768, 52)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cluster = np.repeat(cent, 300, axis=0) + 2e-4 * synth.rows(1800, 768, 53)               # exact scores ~1e-4 apart
+    noisy = np.concatenate([cluster, synth.rows(6000, 768, 54) / np.sqrt(768.0)], axis=0)
+    noisy = _to_bf16_midpoints(noisy[rng.permutation(len(noisy))])
+    q = _to_bf16_midpoints(np.concatenate([cent + 0.01 * synth.rows(6, 768, 55), synth.rows(42, 768, 56) / np.sqrt(768.0)]))
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ix.set_search_mode("coarse")
+    ref = ko.FlatIndexOracle(768, 0)
+    for part, what in ((exact_rows, "rows without rounding error"), (noisy, "worst-case roundings added later")):
+        ix.add(part, normalize=False)
+        ref.add(part)
+        for k in (10, 100):
+            D, I = ix.search(q, k, normalize=False)
+            Dr, Ir = ref.search(q, k)
+            assert_topk_matches(D, I, Dr, Ir, ref.rescore64(q, np.where(Ir < 0, 0, Ir)), f"{what}, k={k}")
+            D3, I3 = ix.search(q[:3], k, normalize=False)      # the 1..4-query sweep: fp32 queries, bf16 rows
+            assert_topk_matches(D3, I3, Dr[:3], Ir[:3], ref.rescore64(q[:3], np.where(Ir[:3] < 0, 0, Ir[:3])), f"{what}, k={k}, 3 queries")
+    ix.close()
+
+
+def _bf16_rne(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def _adversarial_pool(q, n_pool, seed, spread):
+    """Rows near the direction of q whose bf16 rounding errors are ALIGNED with q (the Cauchy-Schwarz worst case the
+    error band has to cover; random errors stay 20-30 x below it): x = xh + s * 0.24 ulp(xh) * sign(q), xh on the
+    bf16 grid, so bf16(x) = xh and x.q = xh.q + s * D.  The rows with the highest coarse scores get s = -1 (decoys),
+    the rows just below them s = +1: the true top-k are rows whose coarse score lies ~1.6 D under the k-th best coarse
+    score, behind every decoy.  Returns (rows, D, coarse scores in float64)."""
+    d = q.shape[0]
+    t = 1.0 + spread * (2.0 * np.random.default_rng(seed).random((n_pool, 1)) - 1.0)
+    xh = _bf16_rne((q[None, :] * t + 0.004 * synth.rows(n_pool, d, seed + 1) / np.sqrt(d)).astype(np.float32))
+    ulp = np.spacing(np.abs(xh)).astype(np.float64) * 65536.0
+    ch = xh.astype(np.float64) @ q.astype(np.float64)
+    D = float(np.median(0.24 * (ulp * np.abs(q.astype(np.float64))[None, :]).sum(axis=1)))
+    s_ = np.where(ch >= ch.max() - 1.6 * D, -1.0, 1.0)
+    x = (xh.astype(np.float64) + s_[:, None] * 0.24 * ulp * np.sign(q.astype(np.float64))[None, :]).astype(np.float32)
+    assert np.array_equal(_bf16_rne(x), xh), "construction: the perturbed rows must round back to the grid rows"
+    return x, D, ch
+
+
+@pytest.mark.parametrize("n_pool,spread", [(600, 0.005), (6000, 0.005)])
+def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool, spread):
+    # (a build whose measured bound is scaled by 0.2 -- -DCZ_EPS_TEST_SCALE=0.2f -- fails this test: the true top-k
+    # rows fall out of a band drawn that narrow; 600 rows: the band is rescored directly, 6000: flagged -> second pass)
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    qs, pools = [], []
+    for j in range(3):
+        qj = synth.rows(1, 768, 61 + j)[0]
+        qj = _bf16_rne(qj / np.linalg.norm(qj))
+        xj, D, ch = _adversarial_pool(qj, n_pool, 70 + 10 * j, spread)
+        exact = xj.astype(np.float64) @ qj.astype(np.float64)
+        top = np.argsort(-exact)[:10]
+        coarse_rank = (ch[None, :] > ch[top][:, None]).sum(axis=1)
+        assert coarse_rank.min() >= 10, "construction: every true top-10 row must sit behind >= 10 decoys in coarse order"
+        assert (ch.max() - ch[top]).min() > 1.2 * D
+        qs.append(qj)
+        pools.append(xj)
+    filler = synth.rows(20000, 768, 99) / np.sqrt(768.0)
+    x = np.concatenate([filler[:7000], pools[0], filler[7000:15000], pools[1], pools[2], filler[15000:]], axis=0)
+    q = np.stack(qs + [synth.rows(1, 768, 100 + j)[0] / np.sqrt(768.0) for j in range(29)]).astype(np.float32)
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=False)
+    ix.set_search_mode("coarse")
+    ref = ko.FlatIndexOracle(768, 0)
+    ref.add(x)
+    for nq in (32, 3):     # the MFMA cascade / the 1..4-query sweep
+        D_, I_ = ix.search(q[:nq], 10, normalize=False)
+        Dr, Ir = ref.search(q[:nq], 10)
+        assert_topk_matches(D_, I_, Dr, Ir, ref.rescore64(q[:nq], np.where(Ir < 0, 0, Ir)), f"aligned rounding errors, nq={nq}")
+    ix.close()
+
+
 def test_coarse_raw_inner_product_wide_norms():
     # un-normalised rows with norms spread over 3 decades: the error bound scales with max ||row||
     x = synth.rows(12000, 768, 41) * (10.0 ** (3.0 * np.random.default_rng(1).random((12000, 1)) - 1.5)).astype(np.float32)

@@ -29,7 +29,17 @@ typedef unsigned short bf16_t;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 // -DLAB_F16: the same loops on fp16 operands (v_mfma_f32_16x16x32_f16): clock / power comparison with bf16
-#ifdef LAB_F16
+#if defined(LAB_I8)
+// -DLAB_I8 (throughput only, results are not checked): the same loops, the same bytes, on v_mfma_i32_16x16x64_i8 --
+// every 16-B fragment is 16 int8 instead of 8 bf16, so a launch does TWICE the printed flops (a K of 768 bf16
+// columns is 1536 int8 columns).  What an int8 coarse scan would gain from the MFMA rate alone.
+typedef int v8in __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f lab_mfma_i8(v8in a, v8in b, v4f c) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, __builtin_bit_cast(v4i_t, c), 0, 0, 0));
+}
+#define LAB_MFMA(A_, B_, C_, X_, Y_, Z_) lab_mfma_i8(A_, B_, C_)
+#elif defined(LAB_F16)
 typedef _Float16 v8in __attribute__((ext_vector_type(8)));
 #define LAB_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
 #else

@@ -55,7 +55,11 @@ struct css_index {
     int search_mode = CSS_SEARCH_AUTO;
     const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
     uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
-    int* maxn2 = nullptr;          // device, 2 words: bits of max ||row||^2 and of max ||row - bf16(row)||^2 (cz_eps)
+    int* maxn2 = nullptr;          // device, 3 words: bits of max ||row||^2, max ||row - bf16(row)||^2, max ||row - int8(row)||^2 (cz_eps)
+    // int8 shadow rows of the 1..4-query sweep (kept next to the bf16 ones when there is room): byte = 128 + round(x / s),
+    // s = max|x| / 127 per row
+    unsigned char* x8 = nullptr;
+    float* x8s = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 256;
     // reusable workspaces (grown on demand, guarded by ws_mu)
@@ -131,21 +135,28 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
                                                      float* __restrict__ norm2, int64_t n, int dim, int dpad,
                                                      int normalize, uint64_t seed, int64_t first_row,
                                                      unsigned short* __restrict__ dsth, int* __restrict__ maxn2,
-                                                     float* __restrict__ err2_out) {
+                                                     float* __restrict__ err2_out, unsigned char* __restrict__ dst8,
+                                                     float* __restrict__ dst8s) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float* s = SYNTH ? nullptr : src + row * (int64_t)dim;
     const uint64_t base = (uint64_t)((first_row + row) * (int64_t)dim);
-    float ss = 0.f;
+    float ss = 0.f, amax = 0.f;
     for (int c = lane; c < dim; c += 64) {
         float v = SYNTH ? css_synth_normal(seed, base + (uint64_t)c) : s[c];
         ss = fmaf(v, v, ss);
+        amax = fmaxf(amax, fabsf(v));
     }
     ss = wave_allsum(ss);
+    amax = wave_allmax(amax);
     // reference: x / (||x||_2 + 1e-8)  (src/storage.py:349-350, :426)
     const float nrm = sqrtf(ss) + 1e-8f;
     float* d = dst + row * (int64_t)dpad;
+    // int8 shadow row: byte = 128 + rint(v / s8), s8 = max|v| / 127 (of the values as stored, i.e. after normalisation)
+    if (normalize) amax = amax / nrm;
+    const float s8 = amax > 0.f ? amax / 127.f : 1.f, inv8 = amax > 0.f ? 127.f / amax : 0.f;
+    float e8 = 0.f;
     float s2 = 0.f, e2 = 0.f;
     for (int c = lane; c < dpad; c += 64) {
         float v = 0.f;
@@ -159,9 +170,23 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
         s2 = fmaf(v, v, s2);
         const float dv = v - (float)h;   // exact in fp32
         e2 = fmaf(dv, dv, e2);
+        if (dst8) {
+            const float k8 = fminf(fmaxf(rintf(v * inv8), -127.f), 127.f);
+            dst8[row * (int64_t)dpad + c] = (unsigned char)(128 + (int)k8);
+            const float d8 = fmaf(-s8, k8, v);   // v - s8 * k8 with one rounding
+            e8 = fmaf(d8, d8, e8);
+        }
     }
     s2 = wave_allsum(s2);
     e2 = wave_allsum(e2);
+    if (dst8) {
+        e8 = wave_allsum(e8);
+        if (lane == 0) {
+            dst8s[row] = s8;
+            if (maxn2 && e8 > __int_as_float(__hip_atomic_load(maxn2 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                atomicMax(maxn2 + 2, __float_as_int(e8));
+        }
+    }
     if (lane == 0 && norm2) norm2[row] = s2;
     // ||row - bf16(row)||^2: what the rounding actually cost (cz_eps: the measured error band of the candidate scans)
     if (lane == 0 && err2_out) err2_out[row] = e2;
@@ -1222,6 +1247,20 @@ bool want_shadow(css_index* ix, int64_t ncap) {
     return (double)ncap * ix->dpad * 6.0 <= 0.8 * (double)tot;
 }
 
+// int8 rows for the 1..4-query sweep (k_sweep_coarse_i8): only next to bf16 shadow rows, rows of at most 1024
+// elements (the fp32 accumulation term of the sweep's error bound, cz_eps) and 7 bytes per element within 80 % of the HBM
+// (CSS_KNN_I8=0 switches them off).
+bool want_i8(css_index* ix, int64_t ncap) {
+    static const bool env_on = [] {
+        const char* e = getenv("CSS_KNN_I8");
+        return !(e && e[0] == '0');
+    }();
+    if (!env_on || ix->dpad % 64 != 0 || ix->dpad > 1024) return false;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    return (double)ncap * ix->dpad * 7.0 <= 0.8 * (double)tot;
+}
+
 // (Re)allocate the row storage for exactly ncap rows, carrying the ntotal existing rows over.
 int reallocate_rows(css_index* ix, int64_t ncap) {
     float* nxb = nullptr;
@@ -1243,8 +1282,24 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
             nxh = nullptr;
         }
     }
+    // the int8 rows of the few-query sweep ride along with the bf16 ones when 7 bytes per element still fit
+    unsigned char* nx8 = nullptr;
+    float* nx8s = nullptr;
+    if (nxh && (ix->x8 != nullptr || ix->ntotal == 0) && want_i8(ix, ncap)) {
+        if (hipMalloc((void**)&nx8, ((size_t)ncap + 256) * ix->dpad) != hipSuccess ||
+            hipMalloc((void**)&nx8s, ((size_t)ncap + 256) * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (nx8) (void)hipFree(nx8);
+            nx8 = nullptr;
+            nx8s = nullptr;
+        }
+    }
     if (ix->ntotal > 0) {
         if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
+        if (nx8) {
+            CSS_HIP_TRY(hipMemcpyAsync(nx8, ix->x8, (size_t)ix->ntotal * ix->dpad, hipMemcpyDeviceToDevice, ix->stream));
+            CSS_HIP_TRY(hipMemcpyAsync(nx8s, ix->x8s, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+        }
         CSS_HIP_TRY(hipMemcpyAsync(nxb, ix->xb, (size_t)ix->ntotal * ix->dpad * sizeof(float),
                                    hipMemcpyDeviceToDevice, ix->stream));
         CSS_HIP_TRY(hipMemcpyAsync(nn2, ix->xnorm2, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
@@ -1257,9 +1312,13 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
     if (ix->xb) CSS_HIP_TRY(hipFree(ix->xb));
     if (ix->xnorm2) CSS_HIP_TRY(hipFree(ix->xnorm2));
     if (ix->xh) CSS_HIP_TRY(hipFree(ix->xh));
+    if (ix->x8) CSS_HIP_TRY(hipFree(ix->x8));
+    if (ix->x8s) CSS_HIP_TRY(hipFree(ix->x8s));
     ix->xb = nxb;
     ix->xnorm2 = nn2;
     ix->xh = nxh;
+    ix->x8 = nx8;
+    ix->x8s = nx8s;
     ix->shadow = nxh ? 1 : 0;
     ix->cap = ncap;
     return CSS_OK;
@@ -1277,6 +1336,15 @@ int ensure_capacity(css_index* ix, int64_t need) {
             ix->xh = nullptr;
         }
         ix->shadow = ix->xh ? 1 : 0;
+        if (ix->xh && !ix->x8 && want_i8(ix, ix->cap)) {
+            if (hipMalloc((void**)&ix->x8, ((size_t)ix->cap + 256) * ix->dpad) != hipSuccess ||
+                hipMalloc((void**)&ix->x8s, ((size_t)ix->cap + 256) * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (ix->x8) (void)hipFree(ix->x8);
+                ix->x8 = nullptr;
+                ix->x8s = nullptr;
+            }
+        }
     }
     return CSS_OK;
 }
@@ -1288,12 +1356,14 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
     float* dst = ix->xb + (size_t)ix->ntotal * ix->dpad;
     float* n2 = ix->xnorm2 + ix->ntotal;
     unsigned short* dh = ix->xh ? ix->xh + (size_t)ix->ntotal * ix->dpad : nullptr;
+    unsigned char* d8 = ix->x8 ? ix->x8 + (size_t)ix->ntotal * ix->dpad : nullptr;
+    float* d8s = ix->x8 ? ix->x8s + ix->ntotal : nullptr;
     if (synth)
         hipLaunchKernelGGL(k_ingest_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, nullptr, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2, (float*)nullptr);
+                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2, (float*)nullptr, d8, d8s);
     else
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x_dev, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2, (float*)nullptr);
+                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2, (float*)nullptr, d8, d8s);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1301,6 +1371,7 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 // ---- environment switches (experiments and verification): read once, never written afterwards
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
+    bool sweep_i8 = true;       // CSS_KNN_SWEEP=bf16: 1..4 queries sweep the bf16 shadow rows even where int8 rows exist (A/B runs)
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
@@ -1316,6 +1387,7 @@ const KnnEnv& knn_env() {
         KnnEnv e;
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
         if (const char* m = getenv("CSS_KNN_EPS")) e.eps_measured = strcmp(m, "apriori") != 0;
+        if (const char* m = getenv("CSS_KNN_SWEEP")) e.sweep_i8 = strcmp(m, "bf16") != 0;
         if (const char* m = getenv("CSS_KNN_GROWTH")) {
             const int v = atoi(m);
             e.growth = (v == 4 || v == 8 || v == 16) ? v : 0;
@@ -1632,10 +1704,35 @@ int launch_sweep_coarse_t(css_index* ix, const float* qpad, int nq, int64_t coun
     return CSS_OK;
 }
 
+template <int NQ, int TT, bool MAIN>
+int launch_sweep_coarse_i8_t(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
+                             hipStream_t st) {
+    const int steps = TT > 0 ? TT : (ix->dpad / 16 + 15) / 16;
+    const size_t lds = ((size_t)NQ * 256 * steps + NQ) * sizeof(float);
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
+    auto kern = k_sweep_coarse_i8<NQ, TT, MAIN>;
+    int rc;
+    if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, ix->x8, ix->x8s, qpad, ix->cthr, ix->cand_s, ix->cand_i,
+                       ix->cand_n, ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, ix->cur_mask,
+                       ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
+// (the int8 rows exist only next to bf16 shadow rows; a RowView of a shadow-less index never gets here)
+inline bool sweep_uses_i8(const css_index* ix) { return ix->x8 != nullptr && knn_env().sweep_i8; }
+
 template <int NQ>
 int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
                            hipStream_t st) {
     const bool main_stage = stride == 1 && !stage0;
+    if (sweep_uses_i8(ix)) {
+        if (ix->dpad == 768)
+            return main_stage ? launch_sweep_coarse_i8_t<NQ, 3, true>(ix, qpad, nq, count, stride, gm1, stage0, st)
+                              : launch_sweep_coarse_i8_t<NQ, 3, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
+        return launch_sweep_coarse_i8_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
+    }
     if (ix->dpad == 768)
         return main_stage ? launch_sweep_coarse_t<NQ, 6, true>(ix, qpad, nq, count, stride, gm1, stage0, st)
                           : launch_sweep_coarse_t<NQ, 6, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
@@ -1659,9 +1756,13 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nq_pad = sweep ? nq : (nq + CZ_T - 1) / CZ_T * CZ_T;
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
-    const float eps_rel = sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f;
-    // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B
-    const int measured = env.eps_measured ? 1 : 0;
+    // int8 sweep: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127
+    const bool i8 = sweep && sweep_uses_i8(ix);
+    const float eps_rel = i8 ? sqrtf((float)ix->dpad) / 254.f + 0.00048828125f
+                             : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
+    // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B.
+    // measured = the word of maxn2 that holds the rows' error: 1 = bf16 rows, 2 = int8 rows
+    const int measured = env.eps_measured ? (i8 ? 2 : 1) : 0;
     const float* qerr2 = sweep ? nullptr : ix->qerr2 + q0;
     const int l2 = ix->metric == CSS_METRIC_L2 ? 1 : 0;
     const float* xn2 = l2 ? ix->xnorm2 : nullptr;  // L2: coarse score = 2 x.q - ||x||^2
@@ -2001,7 +2102,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
         const int64_t blocks = (nq + 3) / 4;
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, q_dev, ix->qpad,
                            ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll, (unsigned short*)nullptr,
-                           (int*)nullptr, ix->qerr2);
+                           (int*)nullptr, ix->qerr2, (unsigned char*)nullptr, (float*)nullptr);
         CSS_LAUNCH_CHECK();
     }
     if (ix->ntotal == 0) {
@@ -2016,10 +2117,13 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
 
     const int mode = ix->search_mode;
     const bool batch_ok = nq > 16 && k <= kMfmaMaxK && ix->dpad % MF_BK == 0;  // the MFMA scan kernels apply
-    // The cascade costs ~10-16 launches: below these sizes (measured on MI355X, 768-d: 1 query 0.18 vs 0.13 ms at
-    // 10 k rows, crossover ~1.2 M; 8 queries crossover ~0.4 M; 32+ queries always ahead) the exact fp32 kernels
-    // answer sooner, and they are what the product's usual 10^3..10^5-row index gets.
-    const bool coarse_pays = nq > 16 || (nq > 4 ? ix->ntotal >= 400000 : ix->ntotal >= 1200000);
+    // Where the candidate path answers sooner than the exact fp32 kernels (tools/knn_crossover.py on MI355X, 768-d, ms
+    // candidate / exact): 5..16 queries at every size (2 k rows 0.07 / 0.15, 100 k 0.16 / 0.28, 1 M 0.44 / 0.93); 1..4
+    // queries with the reference's k' = 100 at every size too (2 k 0.065 / 0.134, 100 k 0.13 / 0.17, 1 M 0.32 / 0.66:
+    // the exact kernels keep k-entry lists per block), with k = 10 from ~100 k rows on (50 k 0.093 / 0.074, 100 k
+    // 0.099 / 0.119, 1 M 0.25 / 0.64).  Round 2 switched at 1.2 M / 0.4 M rows: the cascade has since lost most of its
+    // fixed cost and the few-query sweep reads int8 rows.
+    const bool coarse_pays = nq > 4 || k > 32 || ix->ntotal >= 100000;
     const bool want_split = mode == CSS_SEARCH_SPLIT || env.batch == 1;   // split-operand candidate scan from the fp32 rows
     const bool want_candidates = env.batch == 0 && (mode == CSS_SEARCH_COARSE || (mode == CSS_SEARCH_AUTO && coarse_pays));
     if (want_candidates && ix->xh != nullptr) {
@@ -2097,8 +2201,8 @@ int css_index_create(int dim, int metric, int device, css_index** out) {
         return css::hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
     }
     e = hipEventCreateWithFlags(&ix->ingest_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->maxn2, 3 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(ix->maxn2, 0, 3 * sizeof(int));
     // (null-stream memset vs the non-blocking streams every later launch uses: order it here, once)
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -2117,7 +2221,7 @@ int css_index_free(css_index* ix) {
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
-    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->gthr, ix->qsplit,
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
                     ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};
@@ -2139,7 +2243,7 @@ int css_index_reset(css_index* ix) {
     DeviceGuard g(ix->device);
     if (ix->ingest_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ingest_ev, 0));
     if (ix->ws_pending) CSS_HIP_TRY(hipStreamWaitEvent(ix->stream, ix->ws_ev, 0));   // a search enqueued on another stream still reads maxn2
-    CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, 2 * sizeof(int), ix->stream));
+    CSS_HIP_TRY(hipMemsetAsync(ix->maxn2, 0, 3 * sizeof(int), ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;
 }
@@ -2236,6 +2340,12 @@ int css_index_set_shadow(css_index* ix, int policy) {
     if (ix->xh) {  // start over: the next add decides again
         CSS_HIP_TRY(hipFree(ix->xh));
         ix->xh = nullptr;
+    }
+    if (ix->x8) {
+        CSS_HIP_TRY(hipFree(ix->x8));
+        CSS_HIP_TRY(hipFree(ix->x8s));
+        ix->x8 = nullptr;
+        ix->x8s = nullptr;
     }
     ix->shadow = -1;
     return CSS_OK;

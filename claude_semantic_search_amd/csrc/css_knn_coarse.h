@@ -943,6 +943,138 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
     }
 }
 
+// The same sweep over the INT8 shadow rows (css_index: byte = 128 + round(x / s), s = max|x| / 127 per row): half the
+// bytes of the bf16 sweep.  score = s * (sum_i byte_i q_i - 128 sum_i q_i); a lane converts its 16 bytes of a 16-B
+// chunk with v_cvt_f32_ubyte0..3 and accumulates 16 * steps products in order, the 16 lanes of a row add up in a
+// 4-step tree (the fp32 accumulation term of the error bound, cz_eps, counts on that depth).  The query sits in LDS
+// permuted -- element 256 t + 16 sub + 4 r + e at 256 t + 64 r + 4 sub + e -- so that the 16 lanes of a row read 256
+// contiguous bytes per ds_read_b128.  TT = dpad / 256 when that is exact (768: 3), else 0 = run-time steps.
+template <int NQ, int TT, bool MAIN>
+__global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __restrict__ x8, const float* __restrict__ x8s,
+                                                         const float* __restrict__ qpad, const float* __restrict__ thr,
+                                                         float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
+                                                         int* __restrict__ cand_n, int64_t ntotal, int dpad, int nq,
+                                                         int64_t count, int64_t stride, int gm1, int stage0,
+                                                         const uint32_t* __restrict__ mask, const float* __restrict__ xn2) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][256 * steps] permuted, then [NQ] offsets
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
+    const int chunks = dpad >> 4;                       // 16-B chunks per row (dpad is a multiple of 64)
+    const int steps = TT > 0 ? TT : (chunks + 15) / 16;
+    const int qlen = 256 * steps;
+    float* qoff = qs + NQ * qlen;
+    for (int i = tid; i < NQ * qlen; i += 256) {
+        const int j = i / qlen, pos = i - j * qlen;
+        const int t = pos >> 8, r = (pos >> 6) & 3, sb = (pos >> 2) & 15, e = pos & 3;
+        const int col = 256 * t + 16 * sb + 4 * r + e;
+        qs[i] = (j < nq && col < dpad) ? qpad[(size_t)j * dpad + col] : 0.f;
+    }
+    __syncthreads();
+    if (wave == 0) {   // 128 * sum of the query's elements (the offset of the unsigned bytes)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            float a = 0.f;
+            for (int i = lane; i < qlen; i += 64) a += qs[j * qlen + i];
+            a = wave_allsum(a);
+            if (lane == 0) qoff[j] = 128.f * a;
+        }
+    }
+    float my_thr = INFINITY;  // lane `sub` looks after query `sub`
+    if (sub < nq && !stage0) my_thr = thr[sub];
+    __syncthreads();
+    float my_off = sub < NQ ? qoff[sub < NQ ? sub : 0] : 0.f;
+    for (int64_t u = blockIdx.x; u < count; u += gridDim.x) {
+        const int64_t tile = (stage0 ? u : u + u / gm1 + 1) * stride;
+        const int64_t row_base = tile * CZ_T + wave * 64;
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
+            if constexpr (NQ > 1) asm volatile("" ::: "memory");
+            const int64_t rowA = row_base + it * 4 + rg, rowB = rowA + 4;
+            const int64_t ra_ = rowA < ntotal ? rowA : ntotal - 1, rb_ = rowB < ntotal ? rowB : ntotal - 1;
+            const uint4* pa = reinterpret_cast<const uint4*>(x8 + (size_t)ra_ * dpad) + sub;
+            const uint4* pb = reinterpret_cast<const uint4*>(x8 + (size_t)rb_ * dpad) + sub;
+            const float scA = x8s[ra_], scB = x8s[rb_];
+            float sa[NQ], sb[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
+#define CZ_I8_STEP(T_, VA_, VB_)                                                                              \
+            {                                                                                                  \
+                const unsigned wa[4] = {(VA_).x, (VA_).y, (VA_).z, (VA_).w};                                   \
+                const unsigned wb[4] = {(VB_).x, (VB_).y, (VB_).z, (VB_).w};                                   \
+                _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                               \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                        const float4 qv = *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
+                        sa[j] = fmaf((float)(wa[r] & 0xFFu), qv.x, sa[j]);                                     \
+                        sa[j] = fmaf((float)((wa[r] >> 8) & 0xFFu), qv.y, sa[j]);                              \
+                        sa[j] = fmaf((float)((wa[r] >> 16) & 0xFFu), qv.z, sa[j]);                             \
+                        sa[j] = fmaf((float)(wa[r] >> 24), qv.w, sa[j]);                                       \
+                        sb[j] = fmaf((float)(wb[r] & 0xFFu), qv.x, sb[j]);                                     \
+                        sb[j] = fmaf((float)((wb[r] >> 8) & 0xFFu), qv.y, sb[j]);                              \
+                        sb[j] = fmaf((float)((wb[r] >> 16) & 0xFFu), qv.z, sb[j]);                             \
+                        sb[j] = fmaf((float)(wb[r] >> 24), qv.w, sb[j]);                                       \
+                    }                                                                                          \
+                }                                                                                              \
+            }
+            if constexpr (TT > 0) {
+                uint4 va[TT], vb[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    va[t] = pa[16 * t];
+                    vb[t] = pb[16 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < TT; ++t) CZ_I8_STEP(t, va[t], vb[t])
+            } else {
+                for (int t = 0; t < steps; ++t) {
+                    if (16 * t + sub >= chunks) break;
+                    const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
+                    CZ_I8_STEP(t, xa, xb4)
+                }
+            }
+#undef CZ_I8_STEP
+            float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
+            if (xn2 != nullptr) {
+                xa = xn2[ra_];
+                xb2 = xn2[rb_];
+            }
+            float ma = 0.f, mb = 0.f;  // score of query `sub` for this lane's row
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
+                if (sub == j) {
+                    const float ca = scA * (ra - my_off), cb = scB * (rb - my_off);
+                    ma = xn2 != nullptr ? fmaf(2.f, ca, -xa) : ca;
+                    mb = xn2 != nullptr ? fmaf(2.f, cb, -xb2) : cb;
+                }
+            }
+            if (sub < nq) {
+                const bool okA = rowA < ntotal && CZ_ALLOWED(mask, rowA), okB = rowB < ntotal && CZ_ALLOWED(mask, rowB);
+                if (stage0) {
+                    const size_t o = (size_t)sub * CZ_CAP + (size_t)u * CZ_T + wave * 64 + it * 4 + rg;
+                    cand_s[o] = okA ? ma : -INFINITY;
+                    cand_i[o] = okA ? (uint32_t)rowA : kInvalidRow;
+                    cand_s[o + 4] = okB ? mb : -INFINITY;
+                    cand_i[o + 4] = okB ? (uint32_t)rowB : kInvalidRow;
+                } else {
+                    if (ma >= my_thr && okA) {
+                        const int slot = atomicAdd(&cand_n[(size_t)(sub) * CZ_NS], 1);
+                        if (slot < CZ_CAP) {
+                            cand_s[(size_t)sub * CZ_CAP + slot] = ma;
+                            cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowA;
+                        }
+                    }
+                    if (mb >= my_thr && okB) {
+                        const int slot = atomicAdd(&cand_n[(size_t)(sub) * CZ_NS], 1);
+                        if (slot < CZ_CAP) {
+                            cand_s[(size_t)sub * CZ_CAP + slot] = mb;
+                            cand_i[(size_t)sub * CZ_CAP + slot] = (uint32_t)rowB;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Block-wide bitonic sort of P (power of two, <= CZ_CAP) LDS entries, best first: score desc, id asc.
 __device__ __forceinline__ void cz_bitonic(float* s, uint32_t* id, int P, int tid) {
     for (int size = 2; size <= P; size <<= 1)
@@ -1029,7 +1161,8 @@ __device__ __forceinline__ void cz_rescore_rows(float* s, const uint32_t* id, in
 //                |c - x.q| <= max||x^ - x|| (||q|| + ||q^ - q||) + max||x|| ||q^ - q||  +  2^-11 ||q|| max||x||
 //                (last term: fp32 accumulation, ~10 x its worst case at dim 768).  The error norms are what the
 //                conversions actually produced: max over the index rows (k_ingest_rows, second word of maxn2) and
-//                per query (qerr2; 0 for the sweep, whose queries stay fp32).  ex2 < 0: a priori bound only (the
+//                per query (qerr2; 0 for the sweep, whose queries stay fp32); `measured` = which copy of the rows
+//                the scores came from (maxn2 word 1: bf16 rows, 2: the int8 rows of the sweep).  ex2 < 0: a priori bound only (the
 //                split-operand scan, whose operands are not the bf16 roundings).  Random rows: ~0.41 of a unit
 //                roundoff each, the band is ~2.3 x narrower than the a-priori one and holds ~3 x fewer rows.
 // L2 (score 2 x.q - ||x||^2 vs the directly computed -(||x-q||^2) + ||q||^2): twice that, plus the fp32 cancellation
@@ -1050,7 +1183,7 @@ __device__ __forceinline__ float cz_eps(float eps_rel, float qn2, float mx2, int
     return eps;
 }
 #define CZ_EPS_OF(Q_) cz_eps(eps_rel, qnorm2[Q_], __int_as_float(maxn2_bits[0]), l2,                      \
-                             measured ? __int_as_float(maxn2_bits[1]) : -1.f, (measured && qerr2) ? qerr2[Q_] : 0.f)
+                             measured ? __int_as_float(maxn2_bits[measured]) : -1.f, (measured && qerr2) ? qerr2[Q_] : 0.f)
 
 // One block per query.  Between the stages of the cascade (FINAL = false): sort the candidate buffer, take the k-th
 // best coarse score Tc, publish thr = Tc - 2 eps and keep only the entries >= thr.  After the last stage (FINAL =

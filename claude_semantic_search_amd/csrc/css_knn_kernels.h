@@ -39,6 +39,12 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_allmax(float v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
 // "a is a better hit than b": larger score first, then lower id.
 template <typename IdT>
 __device__ __forceinline__ bool better(float sa, IdT ia, float sb, IdT ib) {

@@ -126,7 +126,8 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * I_dev belong to the caller: read them after synchronising with `stream` as usual. */
 /* Search path: CSS_SEARCH_AUTO (default) selects candidates with a reduced-precision scan
  * inside a rigorous error band and rescores them in fp32 where the multi-launch cascade
- * pays (one query: >= 1.2 M rows; batches always); CSS_SEARCH_EXACT_FP32 forms every score
+ * pays (5 or more queries, or k > 32: always; 1..4 queries with k <= 32: from 100 k rows;
+ * rows are kept as fp32 + bf16 + int8 copies where the HBM allows); CSS_SEARCH_EXACT_FP32 forms every score
  * with fp32 fmaf chains inside the scan kernels (VALU sweeps up to 16 queries, fp32-input
  * MFMA beyond; the parity mode of the tests, and what small indexes use for few queries). */
 #define CSS_SEARCH_AUTO 0

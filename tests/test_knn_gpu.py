@@ -316,28 +316,45 @@ def _bf16_rne(a):
     return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
 
 
-def _adversarial_pool(q, n_pool, seed, spread):
-    """Rows near the direction of q whose bf16 rounding errors are ALIGNED with q (the Cauchy-Schwarz worst case the
-    error band has to cover; random errors stay 20-30 x below it): x = xh + s * 0.24 ulp(xh) * sign(q), xh on the
-    bf16 grid, so bf16(x) = xh and x.q = xh.q + s * D.  The rows with the highest coarse scores get s = -1 (decoys),
-    the rows just below them s = +1: the true top-k are rows whose coarse score lies ~1.6 D under the k-th best coarse
-    score, behind every decoy.  Returns (rows, D, coarse scores in float64)."""
+def _adversarial_pool(q, n_pool, seed, spread, grid="bf16"):
+    """Rows near the direction of q whose rounding errors are ALIGNED with q (the Cauchy-Schwarz worst case the error
+    band has to cover; random errors stay 20-30 x below it): x = xh + s * 0.24 cell(xh) * sign(q), xh on the grid of
+    the reduced-precision copy (bf16 values; or, grid = "int8", the per-row-scaled int8 values of the few-query
+    sweep), so the copy of x is xh and x.q = xh.q + s * D.  The rows with the highest coarse scores get s = -1
+    (decoys), the rows just below them s = +1: the true top-k are rows whose coarse score lies ~1.6 D under the k-th
+    best coarse score, behind every decoy.  Returns (rows, D, coarse scores in float64)."""
     d = q.shape[0]
     t = 1.0 + spread * (2.0 * np.random.default_rng(seed).random((n_pool, 1)) - 1.0)
-    xh = _bf16_rne((q[None, :] * t + 0.004 * synth.rows(n_pool, d, seed + 1) / np.sqrt(d)).astype(np.float32))
-    ulp = np.spacing(np.abs(xh)).astype(np.float64) * 65536.0
-    ch = xh.astype(np.float64) @ q.astype(np.float64)
-    D = float(np.median(0.24 * (ulp * np.abs(q.astype(np.float64))[None, :]).sum(axis=1)))
+    base = (q[None, :] * t + 0.004 * synth.rows(n_pool, d, seed + 1) / np.sqrt(d)).astype(np.float32)
+    q64 = q.astype(np.float64)
+    if grid == "bf16":
+        xh = _bf16_rne(base).astype(np.float64)
+        cell = np.spacing(np.abs(xh.astype(np.float32))).astype(np.float64) * 65536.0
+    else:
+        amax = np.abs(base).max(axis=1, keepdims=True)
+        s8 = (amax / np.float32(127.0)).astype(np.float32)
+        kq = np.clip(np.rint(base / s8), -127, 127).astype(np.float64)
+        xh = s8.astype(np.float64) * kq
+        cell = np.where(np.abs(kq) == 127, 0.0, 1.0) * s8.astype(np.float64)      # the row's largest element stays put
+    ch = xh @ q64
+    D = float(np.median(0.24 * (cell * np.abs(q64)[None, :]).sum(axis=1)))
     s_ = np.where(ch >= ch.max() - 1.6 * D, -1.0, 1.0)
-    x = (xh.astype(np.float64) + s_[:, None] * 0.24 * ulp * np.sign(q.astype(np.float64))[None, :]).astype(np.float32)
-    assert np.array_equal(_bf16_rne(x), xh), "construction: the perturbed rows must round back to the grid rows"
+    x = (xh + s_[:, None] * 0.24 * cell * np.sign(q64)[None, :]).astype(np.float32)
+    if grid == "bf16":
+        assert np.array_equal(_bf16_rne(x), xh.astype(np.float32)), "construction: the perturbed rows must round back to the grid rows"
+    else:   # what k_ingest_rows does: s = max|x| / 127, byte = 128 + rint(x * (127 / max|x|))
+        am = np.abs(x).max(axis=1, keepdims=True)
+        k2 = np.rint((x * (np.float32(127.0) / am)).astype(np.float32))
+        assert np.array_equal(k2, kq.astype(np.float32)), "construction: the perturbed rows must quantise back to the grid rows"
+        ch = ((am / np.float32(127.0)).astype(np.float32).astype(np.float64) * kq) @ q64
     return x, D, ch
 
 
-@pytest.mark.parametrize("n_pool,spread", [(600, 0.005), (6000, 0.005)])
-def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool, spread):
+@pytest.mark.parametrize("n_pool,spread,grid", [(600, 0.005, "bf16"), (6000, 0.005, "bf16"), (1500, 0.02, "int8")])
+def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool, spread, grid):
     # (a build whose measured bound is scaled by 0.2 -- -DCZ_EPS_TEST_SCALE=0.2f -- fails this test: the true top-k
-    # rows fall out of a band drawn that narrow; 600 rows: the band is rescored directly, 6000: flagged -> second pass)
+    # rows fall out of a band drawn that narrow; 600 rows: the band is rescored directly, 6000: flagged -> second pass;
+    # "int8": the grid of the 1..4-query sweep's rows, checked through that sweep)
     from oracle import knn_oracle as ko
     from claude_semantic_search_amd.flat_index import IndexFlatIP
 
@@ -345,7 +362,7 @@ def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool,
     for j in range(3):
         qj = synth.rows(1, 768, 61 + j)[0]
         qj = _bf16_rne(qj / np.linalg.norm(qj))
-        xj, D, ch = _adversarial_pool(qj, n_pool, 70 + 10 * j, spread)
+        xj, D, ch = _adversarial_pool(qj, n_pool, 70 + 10 * j, spread, grid)
         exact = xj.astype(np.float64) @ qj.astype(np.float64)
         top = np.argsort(-exact)[:10]
         coarse_rank = (ch[None, :] > ch[top][:, None]).sum(axis=1)
@@ -361,7 +378,7 @@ def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool,
     ix.set_search_mode("coarse")
     ref = ko.FlatIndexOracle(768, 0)
     ref.add(x)
-    for nq in (32, 3):     # the MFMA cascade / the 1..4-query sweep
+    for nq in ((3,) if grid == "int8" else (32, 3)):     # the MFMA cascade (bf16 rows) / the 1..4-query sweep (int8 rows)
         D_, I_ = ix.search(q[:nq], 10, normalize=False)
         Dr, Ir = ref.search(q[:nq], 10)
         assert_topk_matches(D_, I_, Dr, Ir, ref.rescore64(q[:nq], np.where(Ir < 0, 0, Ir)), f"aligned rounding errors, nq={nq}")

@@ -706,11 +706,14 @@ def _main(argv, platform_factory):
             dt = (time.perf_counter() - t0) / reps
             nat.prof_enable(False)
             ms, n = nat.prof_read("knn_sweep_coarse_main")
-            if n:   # coarse sweep over the bf16 shadow rows: main stage = the row tiles t with t % g != 0 (g = 4)
+            info = index.shadow_info() if hasattr(index, "shadow_info") else {"int8": False}
+            i8 = bool(info.get("int8")) and os.environ.get("CSS_KNN_SWEEP", "") != "bf16"
+            row_b = args.dim * (1 if i8 else 2) + (4 if i8 else 0)   # int8 rows + their fp32 scale, or bf16 rows
+            if n:   # coarse sweep over the int8 (or bf16) shadow rows: main stage = the row tiles t with t % g != 0 (g = 4)
                 ntiles = -(-shard // 256)
                 main_rows = min(((ntiles - 1) - (ntiles - 1) // SWEEP_GROWTH) * 256, shard)
-                kbytes = main_rows * args.dim * 2
-                kname = "k_sweep_coarse<1, 6, true>"
+                kbytes = main_rows * row_b
+                kname = "k_sweep_coarse_i8<1, 3, true>" if i8 else "k_sweep_coarse<1, 6, true>"
             else:   # fp32 sweep (no shadow rows)
                 ms, n = nat.prof_read("knn_scan_small")
                 kbytes = shard * args.dim * 4
@@ -722,10 +725,11 @@ def _main(argv, platform_factory):
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                    "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": kbytes,
                    "latency_ms": dt * 1e3, "cascade_ms": cms / cn if cn else None, "scan_kernel_ms": ms / n if n else None,
-                   # the whole call against the bytes it has to read (all bf16 rows once): the end-to-end HBM fraction
-                   "whole_call_GBps": shard * args.dim * 2 / dt / 1e9,
-                   "whole_call_frac_of_peak": shard * args.dim * 2 / dt / 1e9 / HBM_PEAK_GBS,
-                   "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9}
+                   # the whole call against the bytes it has to read (all shadow rows once): the end-to-end HBM fraction
+                   "whole_call_GBps": shard * row_b / dt / 1e9,
+                   "whole_call_frac_of_peak": shard * row_b / dt / 1e9 / HBM_PEAK_GBS,
+                   "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9,
+                   "rows_read_as": "int8 + per-row scale (bf16 rows would be twice the bytes)" if i8 else "bf16"}
             if kq == 10 and roofline is not None:
                 roofline["nq1_k10"] = rec
             extra[f"nq1_k{kq}"] = rec

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "css_index_set_shadow": (c_int, [c_void_p, c_int]),
     "css_index_last_flagged": (c_int, [c_void_p, POINTER(c_int64)]),
     "css_index_last_swept": (c_int, [c_void_p, POINTER(c_int64)]),
+    "css_index_shadow_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "css_index_set_range_rows": (c_int, [c_void_p, c_int64]),
     "css_index_set_id_base": (c_int, [c_void_p, c_int64]),
     "css_index_set_search_mode": (c_int, [c_void_p, c_int]),

@@ -2326,6 +2326,15 @@ int css_index_last_swept(css_index* ix, int64_t* n) {
     return CSS_OK;
 }
 
+int css_index_shadow_info(css_index* ix, int* has_bf16, int* has_int8) {
+    CSS_REQUIRE(ix && has_bf16 && has_int8, "css_index_shadow_info: NULL argument");
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> wl(ix->ws_mu);   // (a RowView of a running enqueue swaps xh)
+    *has_bf16 = ix->xh != nullptr ? 1 : 0;
+    *has_int8 = ix->x8 != nullptr ? 1 : 0;
+    return CSS_OK;
+}
+
 int css_index_set_shadow(css_index* ix, int policy) {
     CSS_REQUIRE(ix, "css_index_set_shadow: NULL index");
     CSS_REQUIRE(policy >= -1 && policy <= 1, "css_index_set_shadow: policy %d outside {-1, 0, 1}", policy);

@@ -164,6 +164,12 @@ class IndexFlat:
         nat.check(nat.lib().css_index_last_swept(self._handle(), ctypes.byref(n)))
         return int(n.value)
 
+    def shadow_info(self) -> dict:
+        """Diagnostics: which reduced-precision copies of the rows the index holds (``{"bf16": bool, "int8": bool}``)."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        nat.check(nat.lib().css_index_shadow_info(self._handle(), ctypes.byref(a), ctypes.byref(b)))
+        return {"bf16": bool(a.value), "int8": bool(b.value)}
+
     def set_shadow(self, policy: Optional[bool]) -> None:
         """bf16 shadow rows (operand of the candidate scans, +50 % HBM): ``None`` = keep them while they
         fit (default), ``False`` = never, ``True`` = always.  Only on an empty index; results do not change."""

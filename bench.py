@@ -19,7 +19,8 @@ The JSON line also carries:
                 launch stream inside this run (css_prof_*); `traffic` = HBM-side bytes per launch
                 from the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes).
                 Sub-objects (same fields): `nq1_k10` -- the single-query search, the reference's real call
-                shape, with the HBM roofline of its main sweep (the north-star's 60 % target); `exact_fp32_mode`
+                shape, with the HBM roofline of its main sweep over the bytes that sweep reads (int8 rows + row
+                scales where the index keeps them, else bf16 rows; the north-star's 60 % target); `exact_fp32_mode`
                 -- every score formed by fp32 fmaf chains; `encode` -- batch-256 x 384 encoder forward
                 (BASELINE configs[2]) with chunks/s and its bf16-MFMA roofline (the 40 % target).
   cpu_baseline  the CPU oracle (kind "port") timed on this box's host cores on a bounded sample of the same

@@ -165,6 +165,44 @@ def test_incremental_adds_and_growth():
     assert ix.ntotal == 0
 
 
+def test_int8_rows_follow_growth_reset_and_shadow_policy():
+    """The int8 rows of the 1..4-query sweep live and die with the bf16 shadow rows: carried over when the row table
+    is reallocated, restarted after a reset, absent without shadow rows -- and single-query results stay the oracle's."""
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ix.set_search_mode("coarse")
+    ref = ko.FlatIndexOracle(768)
+    q = ko.normalize_rows(synth.rows(3, 768, 510))
+    total = 0
+    for step, n in enumerate([700, 900, 5000, 20000]):     # each add outgrows the capacity: three reallocations
+        x = synth.rows(n, 768, 610 + step)
+        ix.add(x, normalize=True)
+        ref.add(ko.normalize_rows(x))
+        total += n
+        assert ix.shadow_info() == {"bf16": True, "int8": True}
+        for nq in (1, 3):
+            D, I = ix.search(q[:nq], 10)
+            Dr, Ir = ref.search(q[:nq], 10)
+            assert_topk_matches(D, I, Dr, Ir, ref.rescore64(q[:nq], Ir), f"{total} rows, {nq} queries")
+    ix.reset()
+    x = synth.rows(3000, 768, 620)
+    ix.add(x, normalize=True)
+    ref2 = ko.FlatIndexOracle(768)
+    ref2.add(ko.normalize_rows(x))
+    assert ix.shadow_info() == {"bf16": True, "int8": True}
+    D, I = ix.search(q[:1], 10)
+    Dr, Ir = ref2.search(q[:1], 10)
+    assert_topk_matches(D, I, Dr, Ir, ref2.rescore64(q[:1], Ir), "after reset")
+    ix.close()
+    ns = IndexFlatIP(768)
+    ns.set_shadow(False)
+    ns.add(x, normalize=True)
+    assert ns.shadow_info() == {"bf16": False, "int8": False}
+    ns.close()
+
+
 def test_id_base_and_merge_parts_match_whole():
     """Row-partitioned shards + merge == one index, on one GPU."""
     import ctypes

@@ -56,8 +56,8 @@ struct css_index {
     const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
     uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
     int* maxn2 = nullptr;          // device, 3 words: bits of max ||row||^2, max ||row - bf16(row)||^2, max ||row - int8(row)||^2 (cz_eps)
-    // int8 shadow rows of the 1..4-query sweep (kept next to the bf16 ones when there is room): byte = 128 + round(x / s),
-    // s = max|x| / 127 per row
+    // int8 shadow rows (kept next to the bf16 ones when there is room): signed byte = round(x / s), s = max|x| / 127 per
+    // row; read by the 1..4-query sweep and by the int8 MFMA scan of batches
     unsigned char* x8 = nullptr;
     float* x8s = nullptr;
     hipStream_t stream = nullptr;
@@ -67,6 +67,8 @@ struct css_index {
     float* qpad = nullptr;    size_t qpad_cap = 0;      // floats
     float* qnorm2 = nullptr;  size_t qnorm2_cap = 0;    // floats
     float* qerr2 = nullptr;   size_t qerr2_cap = 0;     // per query: ||q - bf16(q)||^2 (cz_eps)
+    float* qerr2_i8 = nullptr; size_t qerr2_i8_cap = 0; // per query: ||q - int8(q)||^2 (int8 MFMA scan)
+    float* qscale = nullptr;  size_t qscale_cap = 0;    // per query: scale of its int8 row
     unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
     // reference: x / (||x||_2 + 1e-8)  (src/storage.py:349-350, :426)
     const float nrm = sqrtf(ss) + 1e-8f;
     float* d = dst + row * (int64_t)dpad;
-    // int8 shadow row: byte = 128 + rint(v / s8), s8 = max|v| / 127 (of the values as stored, i.e. after normalisation)
+    // int8 shadow row: byte = rint(v / s8), s8 = max|v| / 127 (of the values as stored, i.e. after normalisation)
     if (normalize) amax = amax / nrm;
     const float s8 = amax > 0.f ? amax / 127.f : 1.f, inv8 = amax > 0.f ? 127.f / amax : 0.f;
     float e8 = 0.f;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
         e2 = fmaf(dv, dv, e2);
         if (dst8) {
             const float k8 = fminf(fmaxf(rintf(v * inv8), -127.f), 127.f);
-            dst8[row * (int64_t)dpad + c] = (unsigned char)(128 + (int)k8);
+            dst8[row * (int64_t)dpad + c] = (unsigned char)((int)k8 & 0xFF);   // signed int8 (what the int8 MFMA takes)
             const float d8 = fmaf(-s8, k8, v);   // v - s8 * k8 with one rounding
             e8 = fmaf(d8, d8, e8);
         }
@@ -1371,6 +1373,7 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 // ---- environment switches (experiments and verification): read once, never written afterwards
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
+    int batch_i8 = 1;           // CSS_KNN_SCAN=bf16 / i8: batches always scan the bf16 / the int8 shadow rows (1 = where it pays)
     bool sweep_i8 = true;       // CSS_KNN_SWEEP=bf16: 1..4 queries sweep the bf16 shadow rows even where int8 rows exist (A/B runs)
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
@@ -1388,6 +1391,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
         if (const char* m = getenv("CSS_KNN_EPS")) e.eps_measured = strcmp(m, "apriori") != 0;
         if (const char* m = getenv("CSS_KNN_SWEEP")) e.sweep_i8 = strcmp(m, "bf16") != 0;
+        if (const char* m = getenv("CSS_KNN_SCAN")) e.batch_i8 = strcmp(m, "bf16") == 0 ? 0 : (strcmp(m, "i8") == 0 ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_GROWTH")) {
             const int v = atoi(m);
             e.growth = (v == 4 || v == 8 || v == 16) ? v : 0;
@@ -1605,9 +1609,18 @@ int launch_scan_fp32mfma(css_index* ix, int nq, int k, float* D_dev, int64_t* I_
 // After the last stage of a candidate scan: band cut + flagging (one block per query), exact rescoring of the bands
 // (CZ_PARTS work items per query over a fixed grid), sort by exact score + output (one block per query).
 constexpr int kRescoreGrid = 4096;
-int launch_final_select(css_index* ix, int nq, int k, float eps_rel, const float* qerr2, int measured, int l2, int closed_n,
+struct EpsSet {   // what cz_eps needs to know about the operands a scan read
+    float eps_rel;        // a-priori bound relative to ||q|| max||x||
+    const float* qerr2;   // per query ||q - q^||^2 (null: fp32 queries)
+    int measured;         // 0: a-priori only; else the word of maxn2 with the rows' measured error (1 bf16, 2 int8)
+};
+int launch_final_select(css_index* ix, int nq, int k, EpsSet e1, EpsSet e2, int l2, int closed_n,
                         const float* qpad, const float* qnorm2, int* gthr, int* flags, int* nflag, int* flag_list, float* D_dev, int64_t* I_dev, float* thr2,
                         unsigned short* qh2, int f2, hipStream_t st) {
+    // e1: the scan that filled the buffers; e2: the second pass over flagged queries (always bf16 rows and queries)
+    const float eps_rel = e1.eps_rel;
+    const float* qerr2 = e1.qerr2;
+    const int measured = e1.measured;
     hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr, flags,
                        nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, qerr2, measured, ix->fix_s, ix->fix_i, ix->fix_lock);
     hipLaunchKernelGGL(k_rescore_plan, dim3(1), dim3(1024), 0, st, (const int*)ix->cand_n, nq, ix->rs_work, ix->rs_work + 1);
@@ -1615,7 +1628,7 @@ int launch_final_select(css_index* ix, int nq, int k, float eps_rel, const float
                        ix->cand_i, ix->cand_n, CZ_CAP, nq, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, l2, qpad,
                        ix->xb, ix->dpad, (const int*)ix->rs_work, (const int*)(ix->rs_work + 1));
     hipLaunchKernelGGL(k_coarse_final, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, flags, qnorm2, ix->maxn2,
-                       eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2, qerr2, measured);
+                       e2.eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2, e2.qerr2, e2.measured);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1681,7 +1694,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
     hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, gthr,
                        qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
                        ix->cand_n);
-    if ((rc = launch_final_select(ix, nq, k, kSplitEps, nullptr, 0, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
+    if ((rc = launch_final_select(ix, nq, k, EpsSet{kSplitEps, nullptr, 0}, EpsSet{kSplitEps, nullptr, 0}, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
                                   flag_list, D_dev, I_dev, nullptr, nullptr, 0, st)) != CSS_OK)
         return rc;
     return launch_fixup(ix, qpad, nq, k, gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
@@ -1722,6 +1735,18 @@ int launch_sweep_coarse_i8_t(css_index* ix, const float* qpad, int nq, int64_t c
 
 // (the int8 rows exist only next to bf16 shadow rows; a RowView of a shadow-less index never gets here)
 inline bool sweep_uses_i8(const css_index* ix) { return ix->x8 != nullptr && knn_env().sweep_i8; }
+// batches: the int8 MFMA scan -- inner product, rows a whole (even) number of 128-B K steps, the 8-phase loop's shape --
+// where it pays: its candidate band is ~4 x the bf16 scan's (~600 instead of ~25 band rows per query at 10 M rows, all
+// rescored exactly; ~400 + 400 appends per query in the last two stages), a cost per query that does not shrink with
+// the index, while the saving is half of the scan.  Measured (1000 queries, ms int8 / bf16): k = 10: 1.25 M rows
+// 1.96 / 1.90, 2.5 M 3.2 / 3.5, 5 M 5.2 / 6.6, 10 M 9.2-9.7 / 12.3; 10 M rows: k = 16 10.1 / 12.6, k = 32 14.0 / 13.0
+// (the 4096-slot buffers start to overflow), k = 64 24.5 / 13.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
+inline bool batch_uses_i8(const css_index* ix, int k) {
+    const KnnEnv& e = knn_env();
+    if (ix->x8 == nullptr || e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || !e.loop8 || e.mfma_shape != 16)
+        return false;
+    return e.batch_i8 == 2 || (k <= 16 && ix->ntotal >= 2000000);
+}
 
 template <int NQ>
 int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
@@ -1756,14 +1781,17 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nq_pad = sweep ? nq : (nq + CZ_T - 1) / CZ_T * CZ_T;
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
-    // int8 sweep: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127
-    const bool i8 = sweep && sweep_uses_i8(ix);
-    const float eps_rel = i8 ? sqrtf((float)ix->dpad) / 254.f + 0.00048828125f
+    // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)
+    const bool i8 = sweep ? sweep_uses_i8(ix) : batch_uses_i8(ix, k);
+    const float i8_rel = sqrtf((float)ix->dpad) / 254.f;
+    const float eps_rel = i8 ? (sweep ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
                              : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
     // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B.
     // measured = the word of maxn2 that holds the rows' error: 1 = bf16 rows, 2 = int8 rows
     const int measured = env.eps_measured ? (i8 ? 2 : 1) : 0;
-    const float* qerr2 = sweep ? nullptr : ix->qerr2 + q0;
+    const float* qerr2 = sweep ? nullptr : (i8 ? ix->qerr2_i8 + q0 : ix->qerr2 + q0);
+    // the second pass over flagged queries reads the bf16 rows with bf16 queries
+    const EpsSet eps_p2{0.0078125f + 0.00048828125f, ix->qerr2 + q0, env.eps_measured ? 1 : 0};
     const int l2 = ix->metric == CSS_METRIC_L2 ? 1 : 0;
     const float* xn2 = l2 ? ix->xnorm2 : nullptr;  // L2: coarse score = 2 x.q - ||x||^2
     int rc;
@@ -1810,7 +1838,8 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // 15.36 GB of shadow rows at the sweep's bandwidth plus ~0.25 ms -- and with k = 100 (the reference's call shape)
     // g = 16 overflows the 4096-slot buffers (~k g candidates per stage) and lands in the exact fix-up: 10 ms.
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
-    const int g = sweep ? env.growth_sweep : (env.growth ? env.growth : (k <= 32 ? 8 : 4));
+    // (int8 scan: its band is ~4 x wider, growth 8 would append ~2500 rows per query in the main stage)
+    const int g = sweep ? env.growth_sweep : (env.growth ? env.growth : ((k <= 32 && !i8) ? 8 : 4));
     struct Stage {
         int64_t stride;
         int ratio;   // stride of the previous stage / this stride (stage 0: unused)
@@ -1824,6 +1853,12 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         if (g0 > 1) sched.push_back({s0 * g0, 0});
         sched.push_back({s0, g0});
         for (int64_t s = s0 / g; s >= 1; s /= g) sched.push_back({s, g});
+        // int8 scan (band ~4 x wider): the last step of 4 is taken as two steps of 2 -- the main stage is then half of
+        // the rows under the threshold of the other half (~3 x fewer appends than 3/4 of the rows under a quarter's)
+        if (i8 && !sweep && g == 4 && sched.size() >= 2 && sched.back().stride == 1 && ntiles >= 64) {
+            sched.back() = {2, 2};
+            sched.push_back({1, 2});
+        }
     }
     const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
     constexpr int kPaceGroups = 512, kPaceStages = 20;
@@ -1831,7 +1866,13 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     if (use_pace && (rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
 
     {
-        if (!sweep) {
+        if (!sweep && i8) {   // int8 query rows (into the same buffer: half its bytes), their scales and error norms
+            if ((rc = grow(&ix->qscale, &ix->qscale_cap, (size_t)nq_pad)) != CSS_OK) return rc;
+            if ((rc = grow(&ix->qerr2_i8, &ix->qerr2_i8_cap, (size_t)q0 + nq_pad)) != CSS_OK) return rc;
+            hipLaunchKernelGGL(k_rows_to_i8, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, qpad,
+                               reinterpret_cast<signed char*>(ix->qh), ix->qscale, ix->qerr2_i8 + q0, nq, nq_pad, ix->dpad);
+            CSS_LAUNCH_CHECK();
+        } else if (!sweep) {
             const int64_t ne = (int64_t)nq_pad * ix->dpad;
             hipLaunchKernelGGL(k_rows_to_bf16, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qh,
                                (int64_t)nq, (int64_t)nq_pad, ix->dpad);
@@ -1846,21 +1887,29 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
-                            int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int, const int*);
+                            int, int64_t, int64_t, int, int*, const uint32_t*, const float*, int, const int*, const float*,
+                            const float*);
     // (the DBG instantiations honour CSS_KNN_DBG; the product kernels carry no timing switches)
     // v_mfma_f32_16x16x32_bf16 by default: same cycles per flop and LDS traffic as 32x32x16, but the chip holds a
     // higher clock under it (measured in one session: main stage 11.1 ms vs 12.1 ms); CSS_KNN_MFMA=32 for A/B runs
     const bool m16 = env.mfma_shape == 16;
     // the 8-phase ping-pong loop (k_scan_coarse8) wherever its shape constraints hold; CSS_KNN_LOOP=old for A/B runs
     const bool loop8 = env.loop8 && m16 && ix->dpad % 128 == 0;
-    const scan_fn f_stage0 = loop8 ? k_scan_coarse8<true, false>
-                                   : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>);
-    const scan_fn f_mid = loop8 ? (env.dbg ? k_scan_coarse8<false, false, true> : k_scan_coarse8<false, false>)
-                                : (env.dbg ? k_scan_coarse<false, false, true>
-                                           : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>));
-    const scan_fn f_main = loop8 ? (env.dbg ? k_scan_coarse8<false, true, true> : k_scan_coarse8<false, true>)
-                                 : (env.dbg ? k_scan_coarse<false, true, true>
-                                            : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>));
+    const bool i8b = i8 && !sweep;   // (batch_uses_i8 implies the 8-phase loop)
+    const scan_fn f_stage0 = i8b ? k_scan_coarse8<true, false, false, CZ_CAP, true>
+                                 : (loop8 ? k_scan_coarse8<true, false>
+                                          : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>));
+    const scan_fn f_mid = i8b ? k_scan_coarse8<false, false, false, CZ_CAP, true>
+                              : (loop8 ? (env.dbg ? k_scan_coarse8<false, false, true> : k_scan_coarse8<false, false>)
+                                       : (env.dbg ? k_scan_coarse<false, false, true>
+                                                  : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>)));
+    const scan_fn f_main = i8b ? k_scan_coarse8<false, true, false, CZ_CAP, true>
+                               : (loop8 ? (env.dbg ? k_scan_coarse8<false, true, true> : k_scan_coarse8<false, true>)
+                                        : (env.dbg ? k_scan_coarse<false, true, true>
+                                                   : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>)));
+    const unsigned short* scan_rows = i8b ? reinterpret_cast<const unsigned short*>(ix->x8) : ix->xh;
+    const float* scan_xsc = i8b ? ix->x8s : nullptr;
+    const float* scan_qsc = i8b ? ix->qscale : nullptr;
     if (!sweep)
         for (scan_fn f : {f_stage0, f_mid, f_main})
             if ((rc = css::ensure_dynamic_lds((const void*)f, lds, ix->device)) != CSS_OK) return rc;
@@ -1886,14 +1935,14 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
             int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
-            hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
+            hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, scan_rows, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
                                ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg,
-                               (const int*)nullptr);
+                               (const int*)nullptr, scan_xsc, scan_qsc);
             CSS_LAUNCH_CHECK();
         }
         ++stage_idx;
         if (s == 1) {
-            if ((rc = launch_final_select(ix, nq, k, eps_rel, qerr2, measured, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
+            if ((rc = launch_final_select(ix, nq, k, EpsSet{eps_rel, qerr2, measured}, eps_p2, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
                                           I_dev, pass2 ? ix->thr2 : nullptr, pass2 ? ix->qh2 : nullptr, f2, st)) != CSS_OK)
                 return rc;
             break;
@@ -1914,7 +1963,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f_all, dim3(grid), dim3(512), lds, st, ix->xh, ix->qh2, ix->thr2, ix->cand_s2, ix->cand_i2,
                                ix->cand_n2, ix->ntotal, ix->dpad, nqt2, ntiles, (int64_t)1, 1 << 30, pace, ix->cur_mask, xn2, 0,
-                               (const int*)nflag);
+                               (const int*)nflag, (const float*)nullptr, (const float*)nullptr);
         }
         hipLaunchKernelGGL(k_rescore_parts<true>, dim3(kRescoreGrid), dim3(256), 0, st, ix->cand_s2, ix->cand_i2, ix->cand_n2,
                            CZ_CAP2, f2, nflag, flag_list, ix->thr2, l2, qpad, ix->xb, ix->dpad, (const int*)nullptr, (const int*)nullptr);
@@ -2221,7 +2270,7 @@ int css_index_free(css_index* ix) {
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
-    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->gthr, ix->qsplit,
+    void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
                     ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};

@@ -64,6 +64,35 @@ __global__ __launch_bounds__(256) void k_rows_to_bf16_x8(const float* __restrict
     }
 }
 
+// Queries -> int8 rows for the int8 MFMA scan: one wave per query; signed byte = round(q / s), s = max|q| / 127,
+// err2 = ||q - s k||^2 (the query side of the measured error band, cz_eps).  Rows nq .. nq_pad-1: zeros, scale 1.
+__global__ __launch_bounds__(256) void k_rows_to_i8(const float* __restrict__ in, signed char* __restrict__ out,
+                                                    float* __restrict__ scale, float* __restrict__ err2, int nq, int nq_pad,
+                                                    int dpad) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq_pad) return;
+    const float* src = in + (size_t)row * dpad;
+    float amax = 0.f;
+    if (row < nq)
+        for (int c = lane; c < dpad; c += 64) amax = fmaxf(amax, fabsf(src[c]));
+    amax = wave_allmax(amax);
+    const float s8 = amax > 0.f ? amax / 127.f : 1.f, inv8 = amax > 0.f ? 127.f / amax : 0.f;
+    float e2 = 0.f;
+    for (int c = lane; c < dpad; c += 64) {
+        const float v = row < nq ? src[c] : 0.f;
+        const float k8 = fminf(fmaxf(rintf(v * inv8), -127.f), 127.f);
+        out[(size_t)row * dpad + c] = (signed char)(int)k8;
+        const float d8 = fmaf(-s8, k8, v);
+        e2 = fmaf(d8, d8, e2);
+    }
+    e2 = wave_allsum(e2);
+    if (lane == 0) {
+        scale[row] = s8;
+        err2[row] = e2;
+    }
+}
+
 // Band rescoring (k_rescore_parts): a band is split over at most CZ_PARTS blocks
 constexpr int CZ_PARTS = 16;
 // Spacing of the per-query candidate counters, in ints.  1 = packed: a 128-B line apart (32) was tried against the
@@ -148,12 +177,33 @@ _Pragma("unroll")                                                               
                             for (int e = 0; e < 4; ++e) acc[m][n][4 * rg + e] = fmaf(2.f, acc[m][n][4 * rg + e], -xs[e]); \
                     }                                                                                                  \
             }                                                                                                          \
+            if constexpr (I8) { /* int32 accumulators -> scores in units of the query scale: acc * s_row */        \
+_Pragma("unroll")                                                                                                      \
+                for (int n = 0; n < TN; ++n)                                                                           \
+_Pragma("unroll")                                                                                                      \
+                    for (int rg = 0; rg < NR / 4; ++rg) {                                                              \
+                        /* the row scales of this wave's 64 rows came in by LDS-DMA during the K loop (C8_SCALE_ISSUE) */ \
+                        float4 sv4_;                                                                                   \
+                        {                                                                                              \
+                            const unsigned sa_ = sxs_base + (unsigned)CZ_ROFF(n, 4 * rg) * 4u;                         \
+                            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv4_) : "v"(sa_) : "memory"); \
+                        }                                                                                              \
+                        const float svs_[4] = {sv4_.x, sv4_.y, sv4_.z, sv4_.w};                                        \
+_Pragma("unroll")                                                                                                      \
+                        for (int m = 0; m < TM; ++m)                                                                   \
+_Pragma("unroll")                                                                                                      \
+                            for (int e = 0; e < 4; ++e)                                                                \
+                                acc[m][n][4 * rg + e] = (float)__float_as_int(acc[m][n][4 * rg + e]) * svs_[e];        \
+                    }                                                                                                  \
+            }                                                                                                          \
             if (dbg & 1) {                                                                                             \
             } else if constexpr (STAGE0) {                                                                             \
                 const int64_t u = u0 + (int64_t)ct_tile * ustep;                                                       \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
                     const size_t qb = (size_t)(qtile * CZ_T + wr * 128 + CZ_QOFF(m)) * KCAP + (size_t)u * CZ_T + wc * 64; \
+                    float sqm_ = 1.f;                                                                                  \
+                    if constexpr (I8) sqm_ = ssq[wr * 128 + CZ_QOFF(m)];                                               \
 _Pragma("unroll")                                                                                                      \
                     for (int n = 0; n < TN; ++n)                                                                       \
 _Pragma("unroll")                                                                                                      \
@@ -166,7 +216,7 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                             for (int e = 0; e < 4; ++e) {                                                              \
                                 const bool ok = row0 + ro + e < ntotal && CZ_ALLOWED(mask, row0 + ro + e);             \
-                                svp_[e] = ok ? acc[m][n][4 * rg + e] : -INFINITY;                                      \
+                                svp_[e] = ok ? (I8 ? acc[m][n][4 * rg + e] * sqm_ : acc[m][n][4 * rg + e]) : -INFINITY; \
                                 ivp_[e] = ok ? (uint32_t)(row0 + ro + e) : kInvalidRow;                                \
                             }                                                                                          \
                             *reinterpret_cast<float4*>(cand_s + qb + ro) = sv_;                                        \
@@ -216,6 +266,8 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                                 for (int r = 0; r < NR; ++r) h |= (acc[m][n][r] >= thr_q ? 1u : 0u) << (n * NR + r);   \
                             const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + MS * m + lq);                     \
+                            float sqv_ = 1.f;                                                                          \
+                            if constexpr (I8) sqv_ = ssq[wr * 128 + MS * m + lq];                     \
 _Pragma("nounroll")                                                                                                    \
                             while (true) {                                                                             \
                                 const bool has = h != 0u;                                                              \
@@ -233,7 +285,7 @@ _Pragma("nounroll")                                                             
                                 const float t6_ = s0_ ? acc[m][3][1] : acc[m][3][0], t7_ = s0_ ? acc[m][3][3] : acc[m][3][2];\
                                 const float u0_ = s1_ ? t1_ : t0_, u1_ = s1_ ? t3_ : t2_, u2_ = s1_ ? t5_ : t4_, u3_ = s1_ ? t7_ : t6_;\
                                 const float w0_ = s2_ ? u1_ : u0_, w1_ = s2_ ? u3_ : u2_;                              \
-                                const float v_ = s3_ ? w1_ : w0_;                                                      \
+                                const float v_ = I8 ? (s3_ ? w1_ : w0_) * sqv_ : (s3_ ? w1_ : w0_);                                                      \
                                 const int64_t row = row0 + 16 * (bit >> 2) + 4 * lg + (bit & 3);                       \
                                 bool hit = has;                                                                        \
                                 if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);                          \
@@ -311,8 +363,16 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
                                                      uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                      int64_t ntotal, int K, int nqt, int64_t count, int64_t stride,
                                                      int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
-                                                     const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate) {
+                                                     const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate,
+                                                     const float* __restrict__ xsc, const float* __restrict__ qsc) {
     constexpr int KCAP = CZ_CAP;   // candidate slots per query (the shared epilogue macros)
+    constexpr bool I8 = false;     // (the int8 operands exist in k_scan_coarse8 only; xsc / qsc are null here)
+    const float* const ssq = nullptr;
+    const unsigned sxs_base = 0u;
+    (void)xsc;
+    (void)qsc;
+    (void)ssq;
+    (void)sxs_base;
     (void)gate;
     // dbg (CSS_KNN_DBG, timing experiments only, honoured by the DBG instantiation alone so that the product
     // kernel carries no such branches): bit0 skip the epilogue, bit1 skip MFMA + LDS reads, bit2 skip the
@@ -557,20 +617,38 @@ __global__ __launch_bounds__(512) void k_scan_coarse(const unsigned short* __res
 // are those of k_scan_coarse<.., 16> (the epilogue macro is shared).  Needs K % 128 == 0 and 256 slack rows behind
 // the shadow rows (the last tile reads them; their scores are masked by row < ntotal).
 // Measured (10 M x 768, 1000 queries, main stage): see DESIGN.md section 3.
+// one MFMA of the 8-phase loop: bf16 16x16x32, or int8 16x16x64 with the int32 accumulators kept in the v4f registers
+template <bool I8>
+__device__ __forceinline__ v4f c8_mfma(v4f b, v4f a, v4f c) {
+    if constexpr (I8) {
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(v4f, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(v4i_t, b), __builtin_bit_cast(v4i_t, a),
+                                                                              __builtin_bit_cast(v4i_t, c), 0, 0, 0));
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, b), __builtin_bit_cast(v8bf, a), c, 0, 0, 0);
+    }
+}
 constexpr int C8_HT = 16384;
 constexpr int C8_A0 = 0, C8_B0 = 1, C8_B1 = 2, C8_A1 = 3;
 
 // KCAP_T: candidate slots per query (CZ_CAP in the cascade; the second pass over flagged queries has larger buffers).
 // gate (second pass only, else null): number of queries that take part -- the launch is enqueued before that
 // number is known, so blocks whose query tile lies beyond it (all of them when it is 0) return at once.
-template <bool STAGE0, bool MAIN, bool DBG = false, int KCAP_T = CZ_CAP>
+// I8: the operands are the int8 shadow rows (css_index: signed byte = round(x / s), per-row scale s in xsc) and int8
+// queries (k_rows_to_i8, per-query scale in qsc) on v_mfma_i32_16x16x64_i8 -- the same bytes per K step as bf16 carry
+// twice the multiply-adds, a 768-element row is 6 K steps instead of 12.  The integer accumulators (exact; |.| <
+// 2^24 for rows of up to 1024 elements) are converted once per tile, score = acc * s_row * s_query: the row scale is
+// applied in the epilogue, the query scale is folded into the thresholds (thr / s_query) and into the scores that
+// leave the kernel.  Inner product only (the L2 form 2 x.q - ||x||^2 does not factor).
+template <bool STAGE0, bool MAIN, bool DBG = false, int KCAP_T = CZ_CAP, bool I8 = false>
 __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __restrict__ xh,
                                                       const unsigned short* __restrict__ qh,
                                                       const float* __restrict__ thr, float* __restrict__ cand_s,
                                                       uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
                                                       int64_t ntotal, int K, int nqt_arg, int64_t count, int64_t stride,
                                                       int gm1, int* __restrict__ pace_cnt, const uint32_t* __restrict__ mask,
-                                                      const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate) {
+                                                      const float* __restrict__ xn2, int dbg_arg, const int* __restrict__ gate,
+                                                      const float* __restrict__ xsc, const float* __restrict__ qsc) {
     constexpr int MS = 16, TM = 8, TN = 4, NR = 4;
     constexpr int KCAP = KCAP_T;
     const int dbg = DBG ? dbg_arg : 0;   // CSS_KNN_DBG (timing experiments): bit0 skips the epilogue
@@ -594,14 +672,27 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
     const int qtile = jx % nqt;
     const int64_t u0 = xcd + 8 * (jx / nqt), ustep = 8 * slots;
     const int my_ntiles = u0 < count ? (int)((count - u0 + ustep - 1) / ustep) : 0;
-    const int KT = K / 64;                 // even (host check)
+    const unsigned ROWB = I8 ? (unsigned)K : (unsigned)K * 2u;   // bytes per operand row
+    const int KT = (int)(ROWB / 128u);     // K steps of 128 B; even (host check)
     const int total = my_ntiles * KT;
     if (total == 0) return;
 
     __shared__ float sthr[CZ_T];
+    __shared__ float ssq[I8 ? CZ_T : 1];   // I8: the query scales of this query tile
+    __shared__ __attribute__((aligned(16))) float sxs[I8 ? 8 * 64 : 4];   // I8: per wave, the scales of its 64 rows of the current tile
+    const unsigned sxs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sxs[I8 ? wave * 64 : 0];
+    (void)sxs_base;
     __shared__ int space[4];   // landing word of the sibling-pacing counter read
     __shared__ float wl[8][3][CZ_WCAP];   // per-wave hit lists: [score | row | query] (CZ_FLUSH)
-    if (tid < CZ_T) sthr[tid] = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
+    if (tid < CZ_T) {
+        float t_ = STAGE0 ? -INFINITY : thr[qtile * CZ_T + tid];
+        if constexpr (I8) {
+            const float sq_ = qsc[qtile * CZ_T + tid];
+            ssq[tid] = sq_;
+            t_ = t_ / sq_;   // (+-inf stay; scales are > 0)
+        }
+        sthr[tid] = t_;
+    }
     __syncthreads();
     constexpr bool CZ_STAGED = !STAGE0;
     int wcount = 0;                       // entries in this wave's list (wave uniform)
@@ -631,16 +722,16 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
     int dsto[4];
     dsto[C8_A0] = dsto[C8_A1] = (wr * 64 + wc * 16) * 128;
     dsto[C8_B0] = dsto[C8_B1] = (16 * wave) * 128;
-    const unsigned row8 = 8u * (unsigned)K * 2u;
+    const unsigned row8 = 8u * ROWB;
     {
         const int rrA = wc * 16 + prow, srowA = wr * 64 + rrA;
         const unsigned swA = (unsigned)((pchunk ^ ((srowA >> 1) & 7)) << 4);
-        lofs[C8_A0] = (unsigned)(qtile * CZ_T + wr * 128 + rrA) * (unsigned)K * 2u + swA;
-        lofs[C8_A1] = (unsigned)(qtile * CZ_T + wr * 128 + 64 + rrA) * (unsigned)K * 2u + swA;
+        lofs[C8_A0] = (unsigned)(qtile * CZ_T + wr * 128 + rrA) * ROWB + swA;
+        lofs[C8_A1] = (unsigned)(qtile * CZ_T + wr * 128 + 64 + rrA) * ROWB + swA;
         const int srowB = 16 * wave + prow;
         const unsigned swB = (unsigned)((pchunk ^ ((srowB >> 1) & 7)) << 4);
-        lofs[C8_B0] = (unsigned)((srowB >> 5) * 64 + (srowB & 31)) * (unsigned)K * 2u + swB;
-        lofs[C8_B1] = (unsigned)((srowB >> 5) * 64 + 32 + (srowB & 31)) * (unsigned)K * 2u + swB;
+        lofs[C8_B0] = (unsigned)((srowB >> 5) * 64 + (srowB & 31)) * ROWB + swB;
+        lofs[C8_B1] = (unsigned)((srowB >> 5) * 64 + 32 + (srowB & 31)) * ROWB + swB;
     }
 #pragma unroll
     for (int kd = 0; kd < 4; ++kd) {
@@ -649,7 +740,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         ucur[kd] = (int)u0;
         uq[kd] = (int)(u0 / gm1);
         ur[kd] = (int)(u0 % gm1);
-        tbase[kd] = (size_t)tile0 * CZ_T * (size_t)K * 2u;
+        tbase[kd] = (size_t)tile0 * CZ_T * (size_t)ROWB;
     }
 #define C8_ISSUE(KIND_, DB_)                                                                                  \
     {                                                                                                         \
@@ -673,7 +764,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
                     ++uq[KIND_];                                                                              \
                 }                                                                                             \
                 const int64_t t_ = STAGE0 ? (int64_t)ucur[KIND_] * stride : ((int64_t)ucur[KIND_] + uq[KIND_] + 1) * stride + tbias; \
-                tbase[KIND_] = (size_t)t_ * CZ_T * (size_t)K * 2u;                                            \
+                tbase[KIND_] = (size_t)t_ * CZ_T * (size_t)ROWB;                                              \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -684,6 +775,17 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
 
+// I8: the scales of this wave's 64 rows of tile TILE_ travel into sxs by one 4-byte-per-lane LDS-DMA, issued before the
+// tile's K loop: older than every ring DMA of the loop, so the loop's counted vmcnt waits cover it long before the
+// epilogue reads it (fetched in the epilogue itself the loads cost ~3 us per tile of exposed latency: 9.8 vs 8.5 ms
+// per 10 M-row batch).  (Rows beyond ntotal: the slack rows of the scale array.)
+#define C8_SCALE_ISSUE(TILE_)                                                                                 \
+    if constexpr (I8) {                                                                                       \
+        __builtin_amdgcn_global_load_lds(                                                                     \
+            (const __attribute__((address_space(1))) void*)(xsc + (size_t)(TILE_) * CZ_T + wc * 64 + lane),   \
+            (__attribute__((address_space(3))) void*)&sxs[wave * 64], 4, 0, 0);                               \
+    }
+    C8_SCALE_ISSUE(tile0)
     C8_ISSUE(C8_A0, 0)
     C8_ISSUE(C8_B0, 0)
     C8_ISSUE(C8_B1, 0)
@@ -715,9 +817,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                 \
-                    acc[4 * (MH_) + j][2 * (NH_) + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
-                        __builtin_bit_cast(v8bf, B_[n][c]), __builtin_bit_cast(v8bf, a[j][c]),                \
-                        acc[4 * (MH_) + j][2 * (NH_) + n], 0, 0, 0);                                          \
+                    acc[4 * (MH_) + j][2 * (NH_) + n] = c8_mfma<I8>(B_[n][c], a[j][c], acc[4 * (MH_) + j][2 * (NH_) + n]); \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }
 #define C8_SYNC_A()                                   \
@@ -806,6 +906,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
                 ++uqc;
             }
             cur_tile = STAGE0 ? (int64_t)ucmp * stride : ((int64_t)ucmp + uqc + 1) * stride + tbias;
+            if (ct_tile < my_ntiles) C8_SCALE_ISSUE(cur_tile)
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier of wave row 1
@@ -813,6 +914,7 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         if (wcount > 0) CZ_FLUSH();
     }
 #undef C8_KSTEP
+#undef C8_SCALE_ISSUE
 #undef C8_PACE
 #undef C8_SYNC_A
 #undef C8_SYNC_B
@@ -943,9 +1045,9 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
     }
 }
 
-// The same sweep over the INT8 shadow rows (css_index: byte = 128 + round(x / s), s = max|x| / 127 per row): half the
-// bytes of the bf16 sweep.  score = s * (sum_i byte_i q_i - 128 sum_i q_i); a lane converts its 16 bytes of a 16-B
-// chunk with v_cvt_f32_ubyte0..3 and accumulates 16 * steps products in order, the 16 lanes of a row add up in a
+// The same sweep over the INT8 shadow rows (css_index: signed byte = round(x / s), s = max|x| / 127 per row): half the
+// bytes of the bf16 sweep.  With u = byte + 128 (one XOR per dword): score = s * (sum_i u_i q_i - 128 sum_i q_i); a
+// lane converts its 16 bytes of a 16-B chunk with v_cvt_f32_ubyte0..3 and accumulates 16 * steps products in order, the 16 lanes of a row add up in a
 // 4-step tree (the fp32 accumulation term of the error bound, cz_eps, counts on that depth).  The query sits in LDS
 // permuted -- element 256 t + 16 sub + 4 r + e at 256 t + 64 r + 4 sub + e -- so that the 16 lanes of a row read 256
 // contiguous bytes per ds_read_b128.  TT = dpad / 256 when that is exact (768: 3), else 0 = run-time steps.
@@ -998,8 +1100,9 @@ __global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __
             for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
 #define CZ_I8_STEP(T_, VA_, VB_)                                                                              \
             {                                                                                                  \
-                const unsigned wa[4] = {(VA_).x, (VA_).y, (VA_).z, (VA_).w};                                   \
-                const unsigned wb[4] = {(VB_).x, (VB_).y, (VB_).z, (VB_).w};                                   \
+                /* signed bytes -> offset binary (byte + 128) for v_cvt_f32_ubyte: one XOR per four elements */  \
+                const unsigned wa[4] = {(VA_).x ^ 0x80808080u, (VA_).y ^ 0x80808080u, (VA_).z ^ 0x80808080u, (VA_).w ^ 0x80808080u}; \
+                const unsigned wb[4] = {(VB_).x ^ 0x80808080u, (VB_).y ^ 0x80808080u, (VB_).z ^ 0x80808080u, (VB_).w ^ 0x80808080u}; \
                 _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                               \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
                         const float4 qv = *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
@@ -1456,6 +1559,8 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     if (fslot >= 0 && thr2 != nullptr && fslot < f2max) {
         // second coarse pass: coarse scores are x.q (IP) or 2 x.q - ||x||^2 = -(||x - q||^2) + ||q||^2 (L2)
         if (tid == 0) {
+            // (eps_rel / qerr2 / measured here describe the SECOND pass's operands -- the bf16 rows and queries --
+            // whatever the first pass read)
             const float eps = CZ_EPS_OF(q);
             thr2[fslot] = (R >= k && id[k - 1] != kInvalidRow) ? s[k - 1] + (l2 ? qnorm2[q] : 0.f) - eps : -INFINITY;
         }

@@ -91,7 +91,7 @@ int css_index_last_swept(css_index* ix, int64_t* n);
  * while fp32 + bf16 rows fit in 80 % of the HBM (default), 0 = never, 1 = always.  Only on an empty index.
  * Results do not depend on it: without shadow rows batches form their candidate scores from the fp32 rows.
  * Where 7 bytes per element still fit (and rows have at most 1024 elements) the index also keeps INT8 rows
- * (byte = 128 + round(x / s), s = max|x| / 127 per row; +25 %), which searches of 1..4 queries sweep instead
+ * (signed byte = round(x / s), s = max|x| / 127 per row; +25 %), which searches of 1..4 queries sweep instead
  * of the bf16 rows: half the bytes, candidates inside the error band measured at ingest, same exact results. */
 int css_index_set_shadow(css_index* ix, int policy);
 /* Diagnostics: which reduced-precision copies of the rows the index currently holds (0 / 1 each). */

@@ -416,7 +416,9 @@ def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool,
     ix.set_search_mode("coarse")
     ref = ko.FlatIndexOracle(768, 0)
     ref.add(x)
-    for nq in ((3,) if grid == "int8" else (32, 3)):     # the MFMA cascade (bf16 rows) / the 1..4-query sweep (int8 rows)
+    # 32 queries: the MFMA cascade (bf16 rows; the int8 rows under CSS_KNN_SCAN=i8, tests/test_knn_i8_forced_gpu.py);
+    # 3 queries: the 1..4-query sweep (int8 rows)
+    for nq in (32, 3):
         D_, I_ = ix.search(q[:nq], 10, normalize=False)
         Dr, Ir = ref.search(q[:nq], 10)
         assert_topk_matches(D_, I_, Dr, Ir, ref.rescore64(q[:nq], np.where(Ir < 0, 0, Ir)), f"aligned rounding errors, nq={nq}")

@@ -1,0 +1,21 @@
+"""The int8 MFMA scan of batches is chosen by itself only from 2 M rows on (css_index.hip: batch_uses_i8), so the
+small-index parity suite would never reach it: run that whole suite once more in a child process with
+CSS_KNN_SCAN=i8 (the switch is read once per process), every batched inner-product search of it on the int8 rows."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.gpu
+def test_parity_suite_with_the_int8_scan_forced():
+    env = dict(os.environ, CSS_KNN_SCAN="i8")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 failed:\n{tail}\n{r.stderr[-2000:]}"
+    assert " passed" in tail

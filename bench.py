@@ -56,6 +56,17 @@ if SWEEP_GROWTH not in (4, 8, 16):
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3    # dense fp32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak
+INT8_MFMA_PEAK_TF = 5000.0   # dense int8 MFMA peak (MI355X_MICROARCH.md: the cycles of the bf16 form at twice the K)
+
+
+def batch_scan_is_int8(index, k: int, rows: int, dim: int) -> bool:
+    """Mirror of css_index.hip batch_uses_i8: which shadow rows the batched candidate scan reads."""
+    env = os.environ.get("CSS_KNN_SCAN", "")
+    if env == "bf16" or not hasattr(index, "shadow_info") or not index.shadow_info().get("int8"):
+        return False
+    if dim % 256 != 0:
+        return False
+    return env == "i8" or (k <= 16 and rows >= 2_000_000)
 
 
 def parse_args(argv=None):
@@ -654,19 +665,32 @@ def _main(argv, platform_factory):
             # last stage of the cascade (k_scan_coarse8<false,true,..>): the row tiles t with t % g != 0 (g = 8 at
             # k <= 32), i.e. 7/8 of the shard, one bf16 MFMA product per (row, query, k); see css_knn_coarse.h
             ntiles = -(-shard // 256)
-            g_ = cascade_growth(args.k)
+            scan_i8 = batch_scan_is_int8(sh.local, args.k, shard, args.dim)
+            # int8 scan: growth 4 with the last step taken as two steps of 2 -- the main stage is the odd row tiles
+            g_ = 2 if scan_i8 else cascade_growth(args.k)
             main_tiles = (ntiles - 1) - (ntiles - 1) // g_
             main_rows = min(main_tiles * 256, shard)
-            flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops of that launch
-            sweep_bytes = main_rows * args.dim * 2                 # bf16 shadow rows read once
-            roofline = {"bound": "mfma", "kernel": "k_scan_coarse8<false,true> (main stage of the cascade)",
-                        "achieved": flops / avg_s / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None,
+            flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops (multiply-adds x 2) of that launch
+            sweep_bytes = main_rows * (args.dim + 4 if scan_i8 else args.dim * 2)   # shadow rows (int8 + scale / bf16) read once
+            peak_ = INT8_MFMA_PEAK_TF if scan_i8 else BF16_MFMA_PEAK_TF
+            roofline = {"bound": "mfma",
+                        "kernel": ("k_scan_coarse8<false,true,..,int8> (main stage of the cascade, int8 shadow rows)" if scan_i8
+                                   else "k_scan_coarse8<false,true> (main stage of the cascade)"),
+                        "achieved": flops / avg_s / 1e12, "peak": peak_, "unit": "TFLOP/s",
+                        "frac": flops / avg_s / 1e12 / peak_, "traffic": None,
                         "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows, "cascade_growth": g_,
                         "hbm_GBps": sweep_bytes / avg_s / 1e9,
-                        "arithmetic": "bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_16x16x32_bf16; "
-                                      "candidates rescored in fp32",
+                        "arithmetic": ("int8 operands (shadow rows + int8 queries), exact int32 accumulate, v_mfma_i32_16x16x64_i8; "
+                                       "candidates inside the measured error band rescored in fp32") if scan_i8 else
+                                      ("bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_16x16x32_bf16; "
+                                       "candidates rescored in fp32"),
+                        "frac_of_bf16_peak": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF,
                         "executed_mfma_TFLOPs": flops * (-(-args.nq // 256) * 256 / args.nq) / avg_s / 1e12}
+            if scan_i8:
+                roofline["note"] = ("the 8-phase loop moves the same bytes per K step as the bf16 scan and takes the same time per "
+                                    "step (tools/gemm_lab.hip -DLAB_I8): it is bound by its LDS / DMA traffic and the package power, "
+                                    "so against the int8 MFMA peak the fraction is lower than the bf16 scan's against its peak "
+                                    "while the search is faster; CSS_KNN_SCAN=bf16 measures the bf16 scan")
             if "knn_coarse_cascade" in kernels:
                 cms, cn = kernels["knn_coarse_cascade"]
                 roofline["cascade_ms"] = cms / cn           # all stages + selects + rescoring of one search
@@ -677,7 +701,9 @@ def _main(argv, platform_factory):
                         "launches": n, "avg_ms": ms / n}
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
         tr = None
-        for pref in ({"knn_scan_coarse_main": ("k_scan_coarse8<false, true, false, 4096>", "k_scan_coarse<false, true")}.get(dom, ("k_scan_small",))):
+        main_names = ("k_scan_coarse8<false, true, false, 4096, true>",) if (dom == "knn_scan_coarse_main" and scan_i8) else \
+            ("k_scan_coarse8<false, true, false, 4096, false>", "k_scan_coarse8<false, true, false, 4096>", "k_scan_coarse<false, true")
+        for pref in ({"knn_scan_coarse_main": main_names}.get(dom, ("k_scan_small",))):
             tr = tr or pmc_traffic(pref, wl)
         if tr:
             roofline["traffic"] = tr["bytes_per_launch"]
@@ -896,8 +922,8 @@ def _main(argv, platform_factory):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by a bf16 MFMA scan with a "
-                     "rigorous error band, candidates rescored in fp32)",
+            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by an int8 MFMA scan -- bf16 for k > 16 or "
+                     "shards under 2 M rows -- inside a rigorous, measured error band, candidates rescored in fp32)",
             "data": "synthetic" if hip else f"synthetic, on the {plat.name} platform (control-flow rehearsal: NOT a measurement)",
             "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
                                    f"top-{args.k}, {args.rows} rows per GPU",

@@ -69,6 +69,13 @@ struct css_index {
     float* qerr2 = nullptr;   size_t qerr2_cap = 0;     // per query: ||q - bf16(q)||^2 (cz_eps)
     float* qerr2_i8 = nullptr; size_t qerr2_i8_cap = 0; // per query: ||q - int8(q)||^2 (int8 MFMA scan)
     float* qscale = nullptr;  size_t qscale_cap = 0;    // per query: scale of its int8 row
+    // int8 scan policy feedback: the flagged count of the last int8 batch travels to pinned host memory behind the
+    // search (no synchronisation); the next batch looks at it when it has landed (batch_uses_i8)
+    int* h_nflag = nullptr;
+    hipEvent_t nflag_ev = nullptr;
+    bool nflag_pending = false;
+    int nflag_nq = 0;        // queries of the search the pending count belongs to
+    int i8_backoff = 0;      // batches left on the bf16 rows after an int8 batch that flagged too many queries
     unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
@@ -1741,11 +1748,24 @@ inline bool sweep_uses_i8(const css_index* ix) { return ix->x8 != nullptr && knn
 // the index, while the saving is half of the scan.  Measured (1000 queries, ms int8 / bf16): k = 10: 1.25 M rows
 // 1.96 / 1.90, 2.5 M 3.2 / 3.5, 5 M 5.2 / 6.6, 10 M 9.2-9.7 / 12.3; 10 M rows: k = 16 10.1 / 12.6, k = 32 14.0 / 13.0
 // (the 4096-slot buffers start to overflow), k = 64 24.5 / 13.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
-inline bool batch_uses_i8(const css_index* ix, int k) {
+// Its wider band also flags more queries on clustered rows (10 M rows in 20 000 clusters: 23 % of the queries, 14.8 ms
+// against the bf16 scan's 13.3 with none flagged), so the choice adapts per index: when an int8 batch flagged more than
+// 2 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
+inline bool batch_uses_i8(css_index* ix, int k) {
     const KnnEnv& e = knn_env();
     if (ix->x8 == nullptr || e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || !e.loop8 || e.mfma_shape != 16)
         return false;
-    return e.batch_i8 == 2 || (k <= 16 && ix->ntotal >= 2000000);
+    if (e.batch_i8 == 2) return true;
+    if (!(k <= 16 && ix->ntotal >= 2000000)) return false;
+    if (ix->nflag_pending && hipEventQuery(ix->nflag_ev) == hipSuccess) {
+        ix->nflag_pending = false;
+        if ((int64_t)*ix->h_nflag * 50 > ix->nflag_nq) ix->i8_backoff = 16;
+    }
+    if (ix->i8_backoff > 0) {
+        --ix->i8_backoff;
+        return false;
+    }
+    return true;
 }
 
 template <int NQ>
@@ -1899,11 +1919,11 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const scan_fn f_stage0 = i8b ? k_scan_coarse8<true, false, false, CZ_CAP, true>
                                  : (loop8 ? k_scan_coarse8<true, false>
                                           : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>));
-    const scan_fn f_mid = i8b ? k_scan_coarse8<false, false, false, CZ_CAP, true>
+    const scan_fn f_mid = i8b ? (env.dbg ? k_scan_coarse8<false, false, true, CZ_CAP, true> : k_scan_coarse8<false, false, false, CZ_CAP, true>)
                               : (loop8 ? (env.dbg ? k_scan_coarse8<false, false, true> : k_scan_coarse8<false, false>)
                                        : (env.dbg ? k_scan_coarse<false, false, true>
                                                   : (m16 ? k_scan_coarse<false, false, false, 16> : k_scan_coarse<false, false>)));
-    const scan_fn f_main = i8b ? k_scan_coarse8<false, true, false, CZ_CAP, true>
+    const scan_fn f_main = i8b ? (env.dbg ? k_scan_coarse8<false, true, true, CZ_CAP, true> : k_scan_coarse8<false, true, false, CZ_CAP, true>)
                                : (loop8 ? (env.dbg ? k_scan_coarse8<false, true, true> : k_scan_coarse8<false, true>)
                                         : (env.dbg ? k_scan_coarse<false, true, true>
                                                    : (m16 ? k_scan_coarse<false, true, false, 16> : k_scan_coarse<false, true>)));
@@ -1952,6 +1972,18 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
                            ix->fix_i, ix->fix_lock);
         CSS_LAUNCH_CHECK();
     }
+    }
+    if (i8b && env.batch_i8 == 1) {   // feedback for batch_uses_i8 (the last chunk of a search speaks for it)
+        if (ix->h_nflag == nullptr) {
+            CSS_HIP_TRY(hipHostMalloc((void**)&ix->h_nflag, sizeof(int), hipHostMallocDefault));
+            CSS_HIP_TRY(hipEventCreateWithFlags(&ix->nflag_ev, hipEventDisableTiming));
+        }
+        if (!ix->nflag_pending) {
+            CSS_HIP_TRY(hipMemcpyAsync(ix->h_nflag, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            CSS_HIP_TRY(hipEventRecord(ix->nflag_ev, st));
+            ix->nflag_pending = true;
+            ix->nflag_nq = nq;
+        }
     }
     if (pass2) {
         // every launch below reads the flagged count from device memory and returns at once when there is nothing to do
@@ -2270,6 +2302,11 @@ int css_index_free(css_index* ix) {
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
+    if (ix->h_nflag) {   // (the count of the last int8 batch may still be on its way)
+        (void)hipDeviceSynchronize();
+        (void)hipEventDestroy(ix->nflag_ev);
+        (void)hipHostFree(ix->h_nflag);
+    }
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,

@@ -69,13 +69,16 @@ struct css_index {
     float* qerr2 = nullptr;   size_t qerr2_cap = 0;     // per query: ||q - bf16(q)||^2 (cz_eps)
     float* qerr2_i8 = nullptr; size_t qerr2_i8_cap = 0; // per query: ||q - int8(q)||^2 (int8 MFMA scan)
     float* qscale = nullptr;  size_t qscale_cap = 0;    // per query: scale of its int8 row
-    // int8 scan policy feedback: the flagged count of the last int8 batch travels to pinned host memory behind the
-    // search (no synchronisation); the next batch looks at it when it has landed (batch_uses_i8)
-    int* h_nflag = nullptr;
-    hipEvent_t nflag_ev = nullptr;
-    bool nflag_pending = false;
-    int nflag_nq = 0;        // queries of the search the pending count belongs to
-    int i8_backoff = 0;      // batches left on the bf16 rows after an int8 batch that flagged too many queries
+    // int8 policy feedback: the flagged count of the last search that read the int8 rows travels to pinned host memory
+    // behind the search (no synchronisation); the next search of that kind looks at it when it has landed
+    struct I8Feedback {
+        int* h_nflag = nullptr;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+        int nq = 0;        // queries of the search the pending count belongs to
+        int backoff = 0;   // searches left on the bf16 rows after an int8 search that flagged too many queries
+    };
+    I8Feedback fb_batch, fb_sweep;
     unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
@@ -1741,7 +1744,39 @@ int launch_sweep_coarse_i8_t(css_index* ix, const float* qpad, int nq, int64_t c
 }
 
 // (the int8 rows exist only next to bf16 shadow rows; a RowView of a shadow-less index never gets here)
-inline bool sweep_uses_i8(const css_index* ix) { return ix->x8 != nullptr && knn_env().sweep_i8; }
+// Rows whose int8 copy is poor (a few dominant elements set the row scale and the rest rounds to nothing) make the
+// measured band so wide that the buffers overflow and the queries end in the fix-up: results stay exact, the search
+// gets slow.  So the use of the int8 rows adapts per index: `permille` = flagged share of the last int8 search above
+// which the next 16 searches of that kind read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
+inline bool i8_feedback_allows(css_index::I8Feedback& f, int permille) {
+    if (f.pending && hipEventQuery(f.ev) == hipSuccess) {
+        f.pending = false;
+        if ((int64_t)*f.h_nflag * 1000 > (int64_t)f.nq * permille) f.backoff = 16;
+    }
+    if (f.backoff > 0) {
+        --f.backoff;
+        return false;
+    }
+    return true;
+}
+inline int i8_feedback_record(css_index::I8Feedback& f, const int* nflag_dev, int nq, hipStream_t st) {
+    if (f.h_nflag == nullptr) {
+        CSS_HIP_TRY(hipHostMalloc((void**)&f.h_nflag, sizeof(int), hipHostMallocDefault));
+        CSS_HIP_TRY(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+    }
+    if (!f.pending) {
+        CSS_HIP_TRY(hipMemcpyAsync(f.h_nflag, nflag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        CSS_HIP_TRY(hipEventRecord(f.ev, st));
+        f.pending = true;
+        f.nq = nq;
+    }
+    return CSS_OK;
+}
+// 1..4 queries: any flagged query sends the next searches back to the bf16 sweep
+inline bool sweep_uses_i8(css_index* ix) {
+    if (ix->x8 == nullptr || !knn_env().sweep_i8) return false;
+    return i8_feedback_allows(ix->fb_sweep, 0);
+}
 // batches: the int8 MFMA scan -- inner product, rows a whole (even) number of 128-B K steps, the 8-phase loop's shape --
 // where it pays: its candidate band is ~4 x the bf16 scan's (~600 instead of ~25 band rows per query at 10 M rows, all
 // rescored exactly; ~400 + 400 appends per query in the last two stages), a cost per query that does not shrink with
@@ -1757,22 +1792,14 @@ inline bool batch_uses_i8(css_index* ix, int k) {
         return false;
     if (e.batch_i8 == 2) return true;
     if (!(k <= 16 && ix->ntotal >= 2000000)) return false;
-    if (ix->nflag_pending && hipEventQuery(ix->nflag_ev) == hipSuccess) {
-        ix->nflag_pending = false;
-        if ((int64_t)*ix->h_nflag * 50 > ix->nflag_nq) ix->i8_backoff = 16;
-    }
-    if (ix->i8_backoff > 0) {
-        --ix->i8_backoff;
-        return false;
-    }
-    return true;
+    return i8_feedback_allows(ix->fb_batch, 20);
 }
 
 template <int NQ>
 int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
-                           hipStream_t st) {
+                           hipStream_t st, bool i8) {
     const bool main_stage = stride == 1 && !stage0;
-    if (sweep_uses_i8(ix)) {
+    if (i8) {
         if (ix->dpad == 768)
             return main_stage ? launch_sweep_coarse_i8_t<NQ, 3, true>(ix, qpad, nq, count, stride, gm1, stage0, st)
                               : launch_sweep_coarse_i8_t<NQ, 3, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
@@ -1947,9 +1974,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         const int64_t count = stage0 ? W : (W - 1) - (W - 1) / gr;
         if (count > 0 && sweep) {
             ProfScope ps(s == 1 && !stage0 ? "knn_sweep_coarse_main" : "knn_sweep_coarse_stage", st);
-            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, gr - 1, stage0, st);
-            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, gr - 1, stage0, st);
-            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, gr - 1, stage0, st);
+            if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, gr - 1, stage0, st, i8);
+            else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, gr - 1, stage0, st, i8);
+            else rc = launch_sweep_coarse_nq<4>(ix, qpad, nq, count, s, gr - 1, stage0, st, i8);
             if (rc != CSS_OK) return rc;
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
@@ -1973,18 +2000,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         CSS_LAUNCH_CHECK();
     }
     }
-    if (i8b && env.batch_i8 == 1) {   // feedback for batch_uses_i8 (the last chunk of a search speaks for it)
-        if (ix->h_nflag == nullptr) {
-            CSS_HIP_TRY(hipHostMalloc((void**)&ix->h_nflag, sizeof(int), hipHostMallocDefault));
-            CSS_HIP_TRY(hipEventCreateWithFlags(&ix->nflag_ev, hipEventDisableTiming));
-        }
-        if (!ix->nflag_pending) {
-            CSS_HIP_TRY(hipMemcpyAsync(ix->h_nflag, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
-            CSS_HIP_TRY(hipEventRecord(ix->nflag_ev, st));
-            ix->nflag_pending = true;
-            ix->nflag_nq = nq;
-        }
-    }
+    // feedback for batch_uses_i8 / sweep_uses_i8 (the last chunk of a search speaks for it)
+    if (i8b && env.batch_i8 == 1 && (rc = i8_feedback_record(ix->fb_batch, nflag, nq, st)) != CSS_OK) return rc;
+    if (i8 && sweep && (rc = i8_feedback_record(ix->fb_sweep, nflag, nq, st)) != CSS_OK) return rc;
     if (pass2) {
         // every launch below reads the flagged count from device memory and returns at once when there is nothing to do
         ProfScope ps("knn_coarse_pass2", st);
@@ -2302,11 +2320,12 @@ int css_index_free(css_index* ix) {
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->ingest_pending) (void)hipEventSynchronize(ix->ingest_ev);
-    if (ix->h_nflag) {   // (the count of the last int8 batch may still be on its way)
-        (void)hipDeviceSynchronize();
-        (void)hipEventDestroy(ix->nflag_ev);
-        (void)hipHostFree(ix->h_nflag);
-    }
+    for (css_index::I8Feedback* f : {&ix->fb_batch, &ix->fb_sweep})
+        if (f->h_nflag) {   // (the count of the last int8 search may still be on its way)
+            (void)hipDeviceSynchronize();
+            (void)hipEventDestroy(f->ev);
+            (void)hipHostFree(f->h_nflag);
+        }
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,

@@ -425,6 +425,33 @@ def test_coarse_error_band_covers_rounding_errors_aligned_with_the_query(n_pool,
     ix.close()
 
 
+def test_rows_with_dominant_dimensions_stay_exact_whichever_copy_is_read():
+    # sentence embeddings tend to carry a few dimensions far larger than the rest: they set the int8 scale of a row, the
+    # other 766 elements round to almost nothing, the measured band gets wide (queries overflow their buffers and end in
+    # the fix-up).  Results must stay exact, and the index falls back to the bf16 rows for the searches that follow.
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    x = synth.rows(30000, 768, 141)
+    x[:, 5] *= 25.0
+    x[:, 77] = 12.0 + x[:, 77]
+    q = synth.rows(40, 768, 142)
+    q[:, 5] *= 25.0
+    q[:, 77] = 12.0 + q[:, 77]
+    ix = IndexFlatIP(768)
+    ix.add(x, normalize=True)
+    ix.set_search_mode("coarse")
+    ref = ko.FlatIndexOracle(768, 0)
+    ref.add(ko.normalize_rows(x))
+    qn = ko.normalize_rows(q)
+    for rep in range(3):                       # (the first search of each kind reads the int8 rows, the next ones adapt)
+        for nq in (1, 3, 40):
+            D, I = ix.search(q[:nq], 10, normalize=True)
+            Dr, Ir = ref.search(qn[:nq], 10)
+            assert_topk_matches(D, I, Dr, Ir, ref.rescore64(qn[:nq], Ir), f"dominant dimensions, nq={nq}, rep={rep}")
+    ix.close()
+
+
 def test_coarse_raw_inner_product_wide_norms():
     # un-normalised rows with norms spread over 3 decades: the error bound scales with max ||row||
     x = synth.rows(12000, 768, 41) * (10.0 ** (3.0 * np.random.default_rng(1).random((12000, 1)) - 1.5)).astype(np.float32)

@@ -66,7 +66,7 @@ def batch_scan_is_int8(index, k: int, rows: int, dim: int) -> bool:
         return False
     if dim % 256 != 0:
         return False
-    return env == "i8" or (k <= 16 and rows >= 2_000_000)
+    return env == "i8" or (k <= 16 and rows >= 1_200_000)
 
 
 def parse_args(argv=None):
@@ -923,7 +923,7 @@ def _main(argv, platform_factory):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (index, queries and returned scores fp32; candidate selection by an int8 MFMA scan -- bf16 for k > 16 or "
-                     "shards under 2 M rows -- inside a rigorous, measured error band, candidates rescored in fp32)",
+                     "shards under 1.2 M rows -- inside a rigorous, measured error band, candidates rescored in fp32)",
             "data": "synthetic" if hip else f"synthetic, on the {plat.name} platform (control-flow rehearsal: NOT a measurement)",
             "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
                                    f"top-{args.k}, {args.rows} rows per GPU",

@@ -1780,9 +1780,10 @@ inline bool sweep_uses_i8(css_index* ix) {
 // batches: the int8 MFMA scan -- inner product, rows a whole (even) number of 128-B K steps, the 8-phase loop's shape --
 // where it pays: its candidate band is ~4 x the bf16 scan's (~600 instead of ~25 band rows per query at 10 M rows, all
 // rescored exactly; ~400 + 400 appends per query in the last two stages), a cost per query that does not shrink with
-// the index, while the saving is half of the scan.  Measured (1000 queries, ms int8 / bf16): k = 10: 1.25 M rows
-// 1.96 / 1.90, 2.5 M 3.2 / 3.5, 5 M 5.2 / 6.6, 10 M 9.2-9.7 / 12.3; 10 M rows: k = 16 10.1 / 12.6, k = 32 14.0 / 13.0
-// (the 4096-slot buffers start to overflow), k = 64 24.5 / 13.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
+// the index, while the saving is half of the scan.  Measured (1000 queries, ms int8 / bf16, one session): k = 10:
+// 0.6 M rows 1.28 / 1.11, 1 M 1.65 / 1.60, 1.25 M 1.86 / 1.95, 2.5 M 3.0 / 3.5, 5 M 4.9 / 6.6, 10 M 8.8-9.0 / 12.3-13.1;
+// 10 M rows: k = 16 9.3 / 12.6, k = 24 13.0 / 12.9, k = 32 13.5 / 13.0 (the 4096-slot buffers start to overflow);
+// 4096 queries 32.6 / 52.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
 // Its wider band also flags more queries on clustered rows (10 M rows in 20 000 clusters: 23 % of the queries, 14.8 ms
 // against the bf16 scan's 13.3 with none flagged), so the choice adapts per index: when an int8 batch flagged more than
 // 2 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
@@ -1791,7 +1792,7 @@ inline bool batch_uses_i8(css_index* ix, int k) {
     if (ix->x8 == nullptr || e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || !e.loop8 || e.mfma_shape != 16)
         return false;
     if (e.batch_i8 == 2) return true;
-    if (!(k <= 16 && ix->ntotal >= 2000000)) return false;
+    if (!(k <= 16 && ix->ntotal >= 1200000)) return false;
     return i8_feedback_allows(ix->fb_batch, 20);
 }
 
@@ -1981,7 +1982,10 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
-            int* pace = (env.pacing && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
+            // (int8 rows: no sibling pacing -- a row tile fetched by every query-tile block on its own is still only
+            // ~3.5 TB/s worst case at this scan's speed, and the coupling costs more than the HBM traffic it saves:
+            // 9.65 vs 9.02 ms per batch; the bf16 scan reads twice the bytes per row and needs it)
+            int* pace = (env.pacing && !i8b && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
             hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, scan_rows, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
                                ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg,
                                (const int*)nullptr, scan_xsc, scan_qsc);

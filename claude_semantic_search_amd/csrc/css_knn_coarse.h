@@ -153,6 +153,7 @@ __device__ __forceinline__ unsigned cz_wave_or(unsigned v) {
             const unsigned fa_ = wl_base + (unsigned)i_ * 4u;                                                          \
             asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:%4\n\tds_read_b32 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)" \
                          : "=&v"(fs_), "=&v"(fr_), "=&v"(fq_) : "v"(fa_), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory"); \
+            if constexpr (I8) fs_ *= qsc[fq_];   /* the list holds scores in units of the query scale */             \
             const int slot_ = atomicAdd(&cand_n[(size_t)(fq_) * CZ_NS], 1);                                                              \
             if (slot_ < KCAP) {                                                                                      \
                 cand_s[(size_t)fq_ * KCAP + slot_] = fs_;                                                            \
@@ -230,9 +231,11 @@ _Pragma("unroll")                                                               
                    atomic, each waited for in turn: ~0.7 us per hit and wave, 100 us per tile in the early stages of the    \
                    cascade, whose thresholds are loose, and 2 us per tile in the main stage.) */                            \
                 unsigned anym = 0u;                                                                                    \
+                float thrv_[TM];   /* (kept for the hit path: a second LDS read there sits on the tile's critical path) */ \
 _Pragma("unroll")                                                                                                      \
                 for (int m = 0; m < TM; ++m) {                                                                         \
                     const float thr_q = sthr[wr * 128 + CZ_QOFF(m)];                                                   \
+                    thrv_[m] = thr_q;                                                                                  \
                     float mx_ = acc[m][0][0];   /* (v_max3_f32 chain: 8 instructions for the 16 scores of a lane) */   \
 _Pragma("unroll")                                                                                                      \
                     for (int e = 1; e < TN * NR; e += 2) {                                                             \
@@ -259,15 +262,13 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                      \
                         for (int m = 0; m < TM; ++m) {                                                                 \
                             if (((anym >> m) & 1u) == 0u) continue;   /* wave uniform */                               \
-                            const float thr_q = sthr[wr * 128 + MS * m + lq];                                          \
+                            const float thr_q = thrv_[m];                                                              \
                             unsigned h = 0u;                                                                           \
 _Pragma("unroll")                                                                                                      \
                             for (int n = 0; n < TN; ++n)                                                               \
 _Pragma("unroll")                                                                                                      \
                                 for (int r = 0; r < NR; ++r) h |= (acc[m][n][r] >= thr_q ? 1u : 0u) << (n * NR + r);   \
                             const unsigned qv = (unsigned)(qtile * CZ_T + wr * 128 + MS * m + lq);                     \
-                            float sqv_ = 1.f;                                                                          \
-                            if constexpr (I8) sqv_ = ssq[wr * 128 + MS * m + lq];                     \
 _Pragma("nounroll")                                                                                                    \
                             while (true) {                                                                             \
                                 const bool has = h != 0u;                                                              \
@@ -285,7 +286,7 @@ _Pragma("nounroll")                                                             
                                 const float t6_ = s0_ ? acc[m][3][1] : acc[m][3][0], t7_ = s0_ ? acc[m][3][3] : acc[m][3][2];\
                                 const float u0_ = s1_ ? t1_ : t0_, u1_ = s1_ ? t3_ : t2_, u2_ = s1_ ? t5_ : t4_, u3_ = s1_ ? t7_ : t6_;\
                                 const float w0_ = s2_ ? u1_ : u0_, w1_ = s2_ ? u3_ : u2_;                              \
-                                const float v_ = I8 ? (s3_ ? w1_ : w0_) * sqv_ : (s3_ ? w1_ : w0_);                                                      \
+                                const float v_ = s3_ ? w1_ : w0_;                                                      \
                                 const int64_t row = row0 + 16 * (bit >> 2) + 4 * lg + (bit & 3);                       \
                                 bool hit = has;                                                                        \
                                 if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);                          \

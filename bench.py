@@ -979,10 +979,13 @@ def bench_no_shadow(args, dev, stream, log, n=10_000_000):
         dt = (time.perf_counter() - t0) / reps
         nat.prof_enable(False)
         cms, cn = nat.prof_read("knn_rows_to_bf16")
+        ims, icn = nat.prof_read("knn_rows_to_i8")
         nat.prof_reset()
         rec = {"ms_per_batch": dt * 1e3, "queries_per_s": args.nq / dt}
         if cn:
             rec["rows_to_bf16_ms"] = cms / reps
+        if icn:   # the range's scratch rows are int8 where the int8 scan pays (38 GB of conversion traffic instead of 46)
+            rec["rows_to_i8_ms"] = ims / reps
         out["ranges" if mode == "auto" else "split"] = rec
         if ref is None:
             ref = (Dd.clone(), Id.clone())

@@ -105,6 +105,7 @@ struct css_index {
     int* flagB = nullptr;     size_t flagB_cap = 0;      // [nq_pad] list | [1] count: queries left to the exact sweep
     // shadow-less indexes: bf16 rows of one row range at a time + the per-range top-k lists (search_noshadow_ranges)
     unsigned short* xh_tmp = nullptr; size_t xh_tmp_cap = 0;
+    float* x8s_tmp = nullptr; size_t x8s_tmp_cap = 0;   // row scales when the scratch rows are int8
     int64_t range_rows = 0;   // css_index_set_range_rows: rows per range (0: from the free HBM, at most 2^24)
     float* rng_d = nullptr;   int64_t* rng_i = nullptr;  size_t rng_cap = 0;
     const int* last_nswept = nullptr;                    // device counter behind css_index_last_swept
@@ -182,22 +183,20 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
         s2 = fmaf(v, v, s2);
         const float dv = v - (float)h;   // exact in fp32
         e2 = fmaf(dv, dv, e2);
-        if (dst8) {
+        {   // (measured whether or not the int8 row is kept: shadow-less indexes quantise the same way per search)
             const float k8 = fminf(fmaxf(rintf(v * inv8), -127.f), 127.f);
-            dst8[row * (int64_t)dpad + c] = (unsigned char)((int)k8 & 0xFF);   // signed int8 (what the int8 MFMA takes)
+            if (dst8) dst8[row * (int64_t)dpad + c] = (unsigned char)((int)k8 & 0xFF);   // signed int8 (what the int8 MFMA takes)
             const float d8 = fmaf(-s8, k8, v);   // v - s8 * k8 with one rounding
             e8 = fmaf(d8, d8, e8);
         }
     }
     s2 = wave_allsum(s2);
     e2 = wave_allsum(e2);
-    if (dst8) {
-        e8 = wave_allsum(e8);
-        if (lane == 0) {
-            dst8s[row] = s8;
-            if (maxn2 && e8 > __int_as_float(__hip_atomic_load(maxn2 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
-                atomicMax(maxn2 + 2, __float_as_int(e8));
-        }
+    e8 = wave_allsum(e8);
+    if (lane == 0) {
+        if (dst8) dst8s[row] = s8;
+        if (maxn2 && e8 > __int_as_float(__hip_atomic_load(maxn2 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(maxn2 + 2, __float_as_int(e8));
     }
     if (lane == 0 && norm2) norm2[row] = s2;
     // ||row - bf16(row)||^2: what the rounding actually cost (cz_eps: the measured error band of the candidate scans)
@@ -1787,13 +1786,19 @@ inline bool sweep_uses_i8(css_index* ix) {
 // Its wider band also flags more queries on clustered rows (10 M rows in 20 000 clusters: 23 % of the queries, 14.8 ms
 // against the bf16 scan's 13.3 with none flagged), so the choice adapts per index: when an int8 batch flagged more than
 // 2 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
-inline bool batch_uses_i8(css_index* ix, int k) {
+// (`rows`: the rows one cascade covers -- the index, or one range of a shadow-less index)
+inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows) {
     const KnnEnv& e = knn_env();
-    if (ix->x8 == nullptr || e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || !e.loop8 || e.mfma_shape != 16)
+    if (e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || ix->dpad > 1024 || !e.loop8 || e.mfma_shape != 16)
         return false;
     if (e.batch_i8 == 2) return true;
-    if (!(k <= 16 && ix->ntotal >= 1200000)) return false;
+    if (!(k <= 16 && rows >= 1200000)) return false;
     return i8_feedback_allows(ix->fb_batch, 20);
+}
+inline bool batch_uses_i8(css_index* ix, int k) {
+    if (ix->x8 == nullptr) return false;
+    if (ix->xh == nullptr) return true;   // a shadow-less range converted to int8 scratch rows: the choice was made there
+    return batch_i8_wanted(ix, k, ix->ntotal);
 }
 
 template <int NQ>
@@ -1854,7 +1859,10 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // exact scores of their buffered candidates give (k_coarse_select<true>), into CZ_CAP2-slot buffers; only what
     // overflows those too goes on to the exact fp32 sweep.  Round 2 sent every flagged query to that sweep (8 queries
     // per pass over the fp32 rows): 22 flagged of 1000 queries cost 2.9 ms of a 7 ms batch at 1 M clustered rows.
-    const bool pass2 = !sweep && env.pass2 && env.loop8 && env.mfma_shape == 16 && ix->dpad % 128 == 0 && ix->ntotal > CZ_CAP;
+    // (the second pass reads the bf16 rows: a shadow-less range scanned from int8 scratch rows sends its flagged queries
+    // straight to the exact sweep -- and, through the feedback of batch_uses_i8, the next searches to bf16 ranges)
+    const bool pass2 = !sweep && env.pass2 && env.loop8 && env.mfma_shape == 16 && ix->dpad % 128 == 0 && ix->ntotal > CZ_CAP &&
+                       ix->xh != nullptr;
     const int f2 = pass2 ? std::min(nq_pad, kF2Max) : 0;   // (a multiple of CZ_T)
     int* flag_listB = nullptr;
     int* nflagB = nullptr;
@@ -2054,13 +2062,20 @@ struct RowView {
     float* xb;
     float* xnorm2;
     unsigned short* xh;
+    unsigned char* x8;
+    float* x8s;
     int64_t ntotal, id_base;
     const uint32_t* mask;
-    RowView(css_index* i, int64_t row0, int64_t n, unsigned short* xh_rows)
-        : ix(i), xb(i->xb), xnorm2(i->xnorm2), xh(i->xh), ntotal(i->ntotal), id_base(i->id_base), mask(i->cur_mask) {
+    // xh_rows / x8_rows + x8_scales: the range's bf16 OR int8 scratch rows (the other kind null)
+    RowView(css_index* i, int64_t row0, int64_t n, unsigned short* xh_rows, unsigned char* x8_rows = nullptr,
+            float* x8_scales = nullptr)
+        : ix(i), xb(i->xb), xnorm2(i->xnorm2), xh(i->xh), x8(i->x8), x8s(i->x8s), ntotal(i->ntotal), id_base(i->id_base),
+          mask(i->cur_mask) {
         ix->xb = xb + (size_t)row0 * ix->dpad;
         ix->xnorm2 = xnorm2 + row0;
         ix->xh = xh_rows;
+        ix->x8 = x8_rows;
+        ix->x8s = x8_scales;
         ix->ntotal = n;
         ix->id_base = id_base + row0;
         if (mask) ix->cur_mask = mask + row0 / 32;   // (row0 is a multiple of 256)
@@ -2069,6 +2084,8 @@ struct RowView {
         ix->xb = xb;
         ix->xnorm2 = xnorm2;
         ix->xh = xh;
+        ix->x8 = x8;
+        ix->x8s = x8s;
         ix->ntotal = ntotal;
         ix->id_base = id_base;
         ix->cur_mask = mask;
@@ -2114,6 +2131,10 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
     int64_t S = std::min<int64_t>((ntotal + CZ_T - 1) / CZ_T * CZ_T, rows_fit);
     if (S < std::min<int64_t>(ntotal, 1ll << 20)) return CSS_ERR_STATE;
     if (ix->range_rows > 0) S = std::min<int64_t>(S, (ix->range_rows + CZ_T - 1) / CZ_T * CZ_T);
+    // int8 scratch rows where the int8 scan pays (38 GB of conversion traffic per 10 M rows instead of 46, half the scan):
+    // same quantiser as k_ingest_rows, whose running maximum of the int8 error norms covers every row of the index
+    const bool use_i8 = batch_i8_wanted(ix, k, std::min<int64_t>(S, ntotal));
+    if (use_i8 && (rc = grow(&ix->x8s_tmp, &ix->x8s_tmp_cap, (size_t)S + 256)) != CSS_OK) return rc;
     if ((size_t)S * ix->dpad > ix->xh_tmp_cap) {   // (exact size: grow() would double a multi-GB buffer)
         if (ix->xh_tmp) CSS_HIP_TRY(hipFree(ix->xh_tmp));
         ix->xh_tmp = nullptr;
@@ -2143,7 +2164,19 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
     ProfScope all("knn_noshadow_ranges", st);
     for (int r = 0; r < nranges; ++r) {
         const int64_t row0 = (int64_t)r * S, n = std::min<int64_t>(S, ntotal - row0);
-        {
+        if (use_i8) {
+            ProfScope ps("knn_rows_to_i8", st);
+            const float* src_ = ix->xb + (size_t)row0 * ix->dpad;
+            signed char* dst_ = reinterpret_cast<signed char*>(ix->xh_tmp);
+            const dim3 grid_((unsigned)((n + 3) / 4));
+            switch (ix->dpad) {   // (dpad % 256 == 0 and <= 1024: batch_i8_wanted)
+                case 256: hipLaunchKernelGGL(k_rows_to_i8_wide<4>, grid_, dim3(256), 0, st, src_, dst_, ix->x8s_tmp, n); break;
+                case 512: hipLaunchKernelGGL(k_rows_to_i8_wide<8>, grid_, dim3(256), 0, st, src_, dst_, ix->x8s_tmp, n); break;
+                case 768: hipLaunchKernelGGL(k_rows_to_i8_wide<12>, grid_, dim3(256), 0, st, src_, dst_, ix->x8s_tmp, n); break;
+                default: hipLaunchKernelGGL(k_rows_to_i8_wide<16>, grid_, dim3(256), 0, st, src_, dst_, ix->x8s_tmp, n); break;
+            }
+            CSS_LAUNCH_CHECK();
+        } else {
             ProfScope ps("knn_rows_to_bf16", st);
             const int64_t n8 = n * ix->dpad / 8;   // (dpad is a multiple of 64)
             const unsigned blocks = (unsigned)std::min<int64_t>((n8 + 255) / 256, (int64_t)ix->num_cus * 64);
@@ -2154,7 +2187,8 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
             Dp = ix->rng_d + (size_t)r * nq * k;
             Ip = ix->rng_i + (size_t)r * nq * k;
         }
-        RowView view(ix, row0, n, ix->xh_tmp);
+        RowView view(ix, row0, n, use_i8 ? nullptr : ix->xh_tmp, use_i8 ? reinterpret_cast<unsigned char*>(ix->xh_tmp) : nullptr,
+                     use_i8 ? ix->x8s_tmp : nullptr);
         SweepGeom sg;
         if ((rc = make_sweep_geom(ix, k, &sg)) != CSS_OK) return rc;
         const int chunk = coarse_max_chunk(ix);
@@ -2333,7 +2367,7 @@ int css_index_free(css_index* ix) {
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
-                    ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->rng_d, ix->rng_i};
+                    ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->x8s_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);

@@ -1362,20 +1362,27 @@ int ensure_capacity(css_index* ix, int64_t need) {
 
 int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool synth, uint64_t seed,
            int64_t first_row, hipStream_t st) {
-    const int64_t blocks = (n + 3) / 4;
-    CSS_REQUIRE(blocks < (1ll << 31), "ingest: too many rows in one call");
-    float* dst = ix->xb + (size_t)ix->ntotal * ix->dpad;
-    float* n2 = ix->xnorm2 + ix->ntotal;
-    unsigned short* dh = ix->xh ? ix->xh + (size_t)ix->ntotal * ix->dpad : nullptr;
-    unsigned char* d8 = ix->x8 ? ix->x8 + (size_t)ix->ntotal * ix->dpad : nullptr;
-    float* d8s = ix->x8 ? ix->x8s + ix->ntotal : nullptr;
-    if (synth)
-        hipLaunchKernelGGL(k_ingest_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, nullptr, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, seed, first_row, dh, ix->maxn2, (float*)nullptr, d8, d8s);
-    else
-        hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x_dev, dst, n2, n,
-                           ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2, (float*)nullptr, d8, d8s);
-    CSS_LAUNCH_CHECK();
+    // One wave per row: a dispatch carries at most 2^32 work-items, i.e. 2^26 rows -- beyond that the rows were silently
+    // not written (found with an 80 M-row index on one GPU: every search ended in the exact sweep over garbage rows).
+    // 2^24 rows (2^30 work-items) per launch.
+    constexpr int64_t kRowsPerLaunch = 1ll << 24;
+    for (int64_t c0 = 0; c0 < n; c0 += kRowsPerLaunch) {
+        const int64_t nc = std::min<int64_t>(kRowsPerLaunch, n - c0);
+        const int64_t r0 = ix->ntotal + c0;
+        const unsigned blocks = (unsigned)((nc + 3) / 4);
+        float* dst = ix->xb + (size_t)r0 * ix->dpad;
+        float* n2 = ix->xnorm2 + r0;
+        unsigned short* dh = ix->xh ? ix->xh + (size_t)r0 * ix->dpad : nullptr;
+        unsigned char* d8 = ix->x8 ? ix->x8 + (size_t)r0 * ix->dpad : nullptr;
+        float* d8s = ix->x8 ? ix->x8s + r0 : nullptr;
+        if (synth)
+            hipLaunchKernelGGL(k_ingest_rows<true>, dim3(blocks), dim3(256), 0, st, nullptr, dst, n2, nc, ix->dim, ix->dpad,
+                               normalize, seed, first_row + c0, dh, ix->maxn2, (float*)nullptr, d8, d8s);
+        else
+            hipLaunchKernelGGL(k_ingest_rows<false>, dim3(blocks), dim3(256), 0, st, x_dev + (size_t)c0 * ix->dim, dst, n2, nc,
+                               ix->dim, ix->dpad, normalize, 0ull, 0ll, dh, ix->maxn2, (float*)nullptr, d8, d8s);
+        CSS_LAUNCH_CHECK();
+    }
     return CSS_OK;
 }
 

@@ -293,3 +293,29 @@ def test_10m_index_without_shadow_rows_answers_like_the_shadowed_one(big_index):
         Dn, In = ix.search(q, K, normalize=True)
         assert np.array_equal(In, Iref) and np.array_equal(Dn, Dref), rows
     ix.close()
+
+
+def test_rows_beyond_2_pow_26_of_one_add_are_ingested():
+    """The ingest kernel runs one wave per row and a dispatch carries at most 2^32 work-items = 2^26 rows: one add of more
+    rows than that used to leave the rows beyond 2^26 unwritten, silently (an 80 M-row index on one GPU answered from
+    garbage rows through the exact sweep, 12 s per batch).  Narrow rows keep the test at 18 GB: 70 M rows x 4 floats,
+    rows around and far beyond 2^26 read back and compared with the host generator."""
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+    from oracle import knn_oracle as ko
+
+    n, d = 70_000_000, 4
+    ix = IndexFlatIP(d)
+    ix.set_shadow(False)
+    ix.reserve(n)
+    ix.add_synthetic(n, seed=9, first_row=0, normalize=True)
+    assert ix.ntotal == n
+    for r0 in (0, (1 << 24) - 2, (1 << 26) - 2, (1 << 26) + 1_000_003, n - 5):
+        got = ix.reconstruct_n(r0, 4)
+        want = ko.normalize_rows(synth.rows(4, d, 9, first_row=r0))
+        assert np.allclose(got, want, rtol=0, atol=3e-7), (r0, got, want)
+    # and a search sees them: the query equal to a row far beyond 2^26 finds that row first
+    q = ix.reconstruct_n((1 << 26) + 12_345, 1)
+    D_, I_ = ix.search(q, 1, normalize=False)
+    assert abs(float(D_[0, 0]) - 1.0) < 1e-5
+    ix.close()

@@ -871,6 +871,10 @@ def _main(argv, platform_factory):
                 extra["no_shadow_10M"] = bench_no_shadow(args, dev, stream, log)
             except Exception as ex_:
                 extra["no_shadow_10M"] = {"error": repr(ex_)}
+            try:   # SURVEY 8(d) config 5 on ONE GPU: 80 M x 768 = 245.8 GB of fp32 rows, no room for any shadow copy
+                extra["single_gpu_80M"] = bench_80m_one_gpu(args, dev, stream, log)
+            except Exception as ex_:
+                extra["single_gpu_80M"] = {"error": repr(ex_)}
             for nc_ in (20000, 2000):   # 500 and 5000 rows per cluster: a band fits the cascade's buffers / only the second pass's
                 try:
                     extra[f"clustered_10M_{nc_}_clusters"] = bench_clustered(args, dev, stream, log, n=10_000_000, nc=nc_,
@@ -942,6 +946,57 @@ def _main(argv, platform_factory):
 def index_id_base(sh):
     """Global id of this shard's local row 0 (one segment: the synthetic bench index)."""
     return sh.segments[0][1] - sh.segments[0][0] if sh.segments else 0
+
+
+def bench_80m_one_gpu(args, dev, stream, log, n=80_000_000):
+    """BASELINE configs[4]'s index on one GPU (the G = 1 end of its strong-scaling line): the fp32
+    rows alone fill 245.8 of the 288 GB, so batches convert them range by range into int8 scratch rows per search and
+    single queries take the exact fp32 sweep.  Skipped (with the reason) when the rows do not fit this device."""
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    torch.cuda.empty_cache()
+    free_b, total_b = torch.cuda.mem_get_info()
+    need = n * args.dim * 4
+    if args.dim != 768 or free_b < need + (24 << 30):
+        return {"skipped": f"{free_b / 1e9:.0f} GB free, {need / 1e9:.0f} GB of rows + 24 GB of scratch needed"}
+    ix = IndexFlatIP(args.dim, device=dev.index or 0)
+    out = {"rows": n, "nq": args.nq, "k": args.k}
+    try:
+        ix.reserve(n)
+        ix.add_synthetic(n, seed=4, first_row=0, normalize=True, stream=stream)
+        qd = torch.from_numpy(synth.rows(args.nq, args.dim, 5)).to(dev)
+        Dd = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+        Id = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
+        for nq_, reps in ((args.nq, 3), (1, 3)):
+            for _ in range(2):
+                ix.search_dev(qd.data_ptr(), nq_, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+            torch.cuda.synchronize()
+            nat.prof_reset()
+            nat.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ix.search_dev(qd.data_ptr(), nq_, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            nat.prof_enable(False)
+            rec = {"ms": dt * 1e3, "queries_per_s": nq_ / dt}
+            for scope in ("knn_rows_to_i8", "knn_rows_to_bf16", "knn_coarse_cascade", "knn_scan_small"):
+                ms_, cn_ = nat.prof_read(scope)
+                if cn_:
+                    rec[scope + "_ms"] = ms_ / reps
+            if nq_ == 1:
+                rec["fp32_sweep_GBps"] = n * args.dim * 4 / dt / 1e9
+            out[f"nq{nq_}"] = rec
+            nat.prof_reset()
+        log(f"80 M rows on one GPU: {out[f'nq{args.nq}']['ms']:.0f} ms per {args.nq} queries, {out['nq1']['ms']:.1f} ms per single query")
+    finally:
+        ix.close()
+        torch.cuda.empty_cache()
+    return out
 
 
 def bench_no_shadow(args, dev, stream, log, n=10_000_000):

@@ -66,7 +66,7 @@ def batch_scan_is_int8(index, k: int, rows: int, dim: int) -> bool:
         return False
     if dim % 256 != 0:
         return False
-    return env == "i8" or (k <= 16 and rows >= 1_200_000)
+    return env == "i8" or (rows >= 300_000 if k <= 32 else (k <= 128 and rows >= 4_000_000))
 
 
 def parse_args(argv=None):
@@ -926,8 +926,8 @@ def _main(argv, platform_factory):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by an int8 MFMA scan -- bf16 for k > 16 or "
-                     "shards under 1.2 M rows -- inside a rigorous, measured error band, candidates rescored in fp32)",
+            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by an int8 MFMA scan -- bf16 for k > 128 and "
+                     "small shards -- inside a rigorous, measured error band, candidates rescored in fp32)",
             "data": "synthetic" if hip else f"synthetic, on the {plat.name} platform (control-flow rehearsal: NOT a measurement)",
             "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
                                    f"top-{args.k}, {args.rows} rows per GPU",

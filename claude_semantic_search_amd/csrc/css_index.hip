@@ -1389,6 +1389,7 @@ int ingest(css_index* ix, const float* x_dev, int64_t n, int normalize, bool syn
 // ---- environment switches (experiments and verification): read once, never written afterwards
 struct KnnEnv {
     int batch = 0;        // CSS_KNN_BATCH: "split" = 1 (split-operand candidate scan for every batch), "fp32" = 2 (fp32-MFMA scan)
+    bool exact_k = true;        // CSS_KNN_EXACTK=0: two-eps thresholds from coarse scores only in the int8 scan's selects
     int batch_i8 = 1;           // CSS_KNN_SCAN=bf16 / i8: batches always scan the bf16 / the int8 shadow rows (1 = where it pays)
     bool sweep_i8 = true;       // CSS_KNN_SWEEP=bf16: 1..4 queries sweep the bf16 shadow rows even where int8 rows exist (A/B runs)
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
@@ -1407,6 +1408,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_BATCH")) e.batch = std::string(m) == "split" ? 1 : (std::string(m) == "fp32" ? 2 : 0);
         if (const char* m = getenv("CSS_KNN_EPS")) e.eps_measured = strcmp(m, "apriori") != 0;
         if (const char* m = getenv("CSS_KNN_SWEEP")) e.sweep_i8 = strcmp(m, "bf16") != 0;
+        if (const char* m = getenv("CSS_KNN_EXACTK")) e.exact_k = m[0] != '0';
         if (const char* m = getenv("CSS_KNN_SCAN")) e.batch_i8 = strcmp(m, "bf16") == 0 ? 0 : (strcmp(m, "i8") == 0 ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_GROWTH")) {
             const int v = atoi(m);
@@ -1630,7 +1632,7 @@ struct EpsSet {   // what cz_eps needs to know about the operands a scan read
     const float* qerr2;   // per query ||q - q^||^2 (null: fp32 queries)
     int measured;         // 0: a-priori only; else the word of maxn2 with the rows' measured error (1 bf16, 2 int8)
 };
-int launch_final_select(css_index* ix, int nq, int k, EpsSet e1, EpsSet e2, int l2, int closed_n,
+int launch_final_select(css_index* ix, int nq, int k, EpsSet e1, EpsSet e2, bool exact_k, int l2, int closed_n,
                         const float* qpad, const float* qnorm2, int* gthr, int* flags, int* nflag, int* flag_list, float* D_dev, int64_t* I_dev, float* thr2,
                         unsigned short* qh2, int f2, hipStream_t st) {
     // e1: the scan that filled the buffers; e2: the second pass over flagged queries (always bf16 rows and queries)
@@ -1638,7 +1640,8 @@ int launch_final_select(css_index* ix, int nq, int k, EpsSet e1, EpsSet e2, int 
     const float* qerr2 = e1.qerr2;
     const int measured = e1.measured;
     hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr, flags,
-                       nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, qerr2, measured, ix->fix_s, ix->fix_i, ix->fix_lock);
+                       nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, qerr2, measured, ix->fix_s, ix->fix_i, ix->fix_lock,
+                       exact_k ? qpad : (const float*)nullptr, exact_k ? (const float*)ix->xb : (const float*)nullptr, ix->dpad);
     hipLaunchKernelGGL(k_rescore_plan, dim3(1), dim3(1024), 0, st, (const int*)ix->cand_n, nq, ix->rs_work, ix->rs_work + 1);
     hipLaunchKernelGGL(k_rescore_parts<false>, dim3(std::min(kRescoreGrid, nq * CZ_PARTS)), dim3(256), 0, st, ix->cand_s,
                        ix->cand_i, ix->cand_n, CZ_CAP, nq, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, l2, qpad,
@@ -1710,7 +1713,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
     hipLaunchKernelGGL(k_merge_final<METRIC>, dim3(nq), dim3(256), 0, st, ix->part_s, ix->part_i, nstrips, kp, gthr,
                        qnorm2, ix->id_base, D_dev, I_dev, METRIC == CSS_METRIC_L2 ? 1 : 0, ix->cand_s, ix->cand_i,
                        ix->cand_n);
-    if ((rc = launch_final_select(ix, nq, k, EpsSet{kSplitEps, nullptr, 0}, EpsSet{kSplitEps, nullptr, 0}, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
+    if ((rc = launch_final_select(ix, nq, k, EpsSet{kSplitEps, nullptr, 0}, EpsSet{kSplitEps, nullptr, 0}, false, METRIC == CSS_METRIC_L2 ? 1 : 0, kp, qpad, qnorm2, gthr, flags, nflag,
                                   flag_list, D_dev, I_dev, nullptr, nullptr, 0, st)) != CSS_OK)
         return rc;
     return launch_fixup(ix, qpad, nq, k, gthr, flag_list, nflag, ix->fix_s, ix->fix_i, ix->fix_lock, D_dev, I_dev,
@@ -1784,28 +1787,31 @@ inline bool sweep_uses_i8(css_index* ix) {
     return i8_feedback_allows(ix->fb_sweep, 0);
 }
 // batches: the int8 MFMA scan -- inner product, rows a whole (even) number of 128-B K steps, the 8-phase loop's shape --
-// where it pays: its candidate band is ~4 x the bf16 scan's (~600 instead of ~25 band rows per query at 10 M rows, all
-// rescored exactly; ~400 + 400 appends per query in the last two stages), a cost per query that does not shrink with
-// the index, while the saving is half of the scan.  Measured (1000 queries, ms int8 / bf16, one session): k = 10:
-// 0.6 M rows 1.28 / 1.11, 1 M 1.65 / 1.60, 1.25 M 1.86 / 1.95, 2.5 M 3.0 / 3.5, 5 M 4.9 / 6.6, 10 M 8.8-9.0 / 12.3-13.1;
-// 10 M rows: k = 16 9.3 / 12.6, k = 24 13.0 / 12.9, k = 32 13.5 / 13.0 (the 4096-slot buffers start to overflow);
-// 4096 queries 32.6 / 52.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
+// where it pays: its candidate band is wider than the bf16 scan's (with the one-eps thresholds of k_coarse_select ~150
+// instead of ~25 band rows per query at 10 M rows, all rescored exactly, and the k best candidates are scored exactly
+// in every select), costs per query that do not shrink with the index, while the saving is half of the scan.
+// Measured (1000 queries, ms int8 / bf16, one session): k = 10: 0.1 M rows 0.40 / 0.32, 0.2 M 0.57 / 0.49, 0.3 M
+// 0.64 / 0.68, 0.6 M 0.93 / 1.06, 1 M 1.25 / 1.61, 1.25 M 1.42 / 1.95, 2.5 M 2.35 / 3.5, 10 M 7.6-7.8 / 12.3-13.1;
+// 10 M rows: k = 16 7.8 / 12.6, k = 32 8.4 / 12.8, k = 64 9.7 / 13.3, k = 100 10.8 / 13.7, k = 128 11.6 / 14.0; but
+// 1 M rows, k = 100: 3.0 / 2.2, and 64 queries, k = 100, 10 M rows: 3.8 / 3.6 (the selects score k rows per query
+// exactly); 4096 queries, k = 10: 29.0 / 52.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
 // Its wider band also flags more queries on clustered rows (10 M rows in 20 000 clusters: 23 % of the queries, 14.8 ms
 // against the bf16 scan's 13.3 with none flagged), so the choice adapts per index: when an int8 batch flagged more than
 // 2 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
 // (`rows`: the rows one cascade covers -- the index, or one range of a shadow-less index)
-inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows) {
+inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     const KnnEnv& e = knn_env();
     if (e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || ix->dpad > 1024 || !e.loop8 || e.mfma_shape != 16)
         return false;
     if (e.batch_i8 == 2) return true;
-    if (!(k <= 16 && rows >= 1200000)) return false;
+    const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 4000000 && nq >= 256);
+    if (!pays) return false;
     return i8_feedback_allows(ix->fb_batch, 20);
 }
-inline bool batch_uses_i8(css_index* ix, int k) {
+inline bool batch_uses_i8(css_index* ix, int k, int64_t nq) {
     if (ix->x8 == nullptr) return false;
     if (ix->xh == nullptr) return true;   // a shadow-less range converted to int8 scratch rows: the choice was made there
-    return batch_i8_wanted(ix, k, ix->ntotal);
+    return batch_i8_wanted(ix, k, ix->ntotal, nq);
 }
 
 template <int NQ>
@@ -1842,7 +1848,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)
-    const bool i8 = sweep ? sweep_uses_i8(ix) : batch_uses_i8(ix, k);
+    const bool i8 = sweep ? sweep_uses_i8(ix) : batch_uses_i8(ix, k, nq);
     const float i8_rel = sqrtf((float)ix->dpad) / 254.f;
     const float eps_rel = i8 ? (sweep ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
                              : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
@@ -1959,6 +1965,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // the 8-phase ping-pong loop (k_scan_coarse8) wherever its shape constraints hold; CSS_KNN_LOOP=old for A/B runs
     const bool loop8 = env.loop8 && m16 && ix->dpad % 128 == 0;
     const bool i8b = i8 && !sweep;   // (batch_uses_i8 implies the 8-phase loop)
+    // one-eps thresholds from exactly scored top-k candidates (k_coarse_select): the int8 scan, whose band is wide
+    // (CSS_KNN_EXACTK=0 for A/B runs; the scores are inner products: batch_uses_i8)
+    const bool exact_k = i8b && env.exact_k && k * 2 <= CZ_EXK;
     const scan_fn f_stage0 = i8b ? k_scan_coarse8<true, false, false, CZ_CAP, true>
                                  : (loop8 ? k_scan_coarse8<true, false>
                                           : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>));
@@ -2008,14 +2017,15 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
         ++stage_idx;
         if (s == 1) {
-            if ((rc = launch_final_select(ix, nq, k, EpsSet{eps_rel, qerr2, measured}, eps_p2, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
+            if ((rc = launch_final_select(ix, nq, k, EpsSet{eps_rel, qerr2, measured}, eps_p2, exact_k, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
                                           I_dev, pass2 ? ix->thr2 : nullptr, pass2 ? ix->qh2 : nullptr, f2, st)) != CSS_OK)
                 return rc;
             break;
         }
         hipLaunchKernelGGL(k_coarse_select<false>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n,
                            ix->cthr, flags, nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, 0, ix->gthr + q0, qerr2, measured, ix->fix_s,
-                           ix->fix_i, ix->fix_lock);
+                           ix->fix_i, ix->fix_lock, exact_k ? qpad : (const float*)nullptr,
+                           exact_k ? (const float*)ix->xb : (const float*)nullptr, ix->dpad);
         CSS_LAUNCH_CHECK();
     }
     }
@@ -2140,7 +2150,7 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
     if (ix->range_rows > 0) S = std::min<int64_t>(S, (ix->range_rows + CZ_T - 1) / CZ_T * CZ_T);
     // int8 scratch rows where the int8 scan pays (38 GB of conversion traffic per 10 M rows instead of 46, half the scan):
     // same quantiser as k_ingest_rows, whose running maximum of the int8 error norms covers every row of the index
-    const bool use_i8 = batch_i8_wanted(ix, k, std::min<int64_t>(S, ntotal));
+    const bool use_i8 = batch_i8_wanted(ix, k, std::min<int64_t>(S, ntotal), nq);
     if (use_i8 && (rc = grow(&ix->x8s_tmp, &ix->x8s_tmp_cap, (size_t)S + 256)) != CSS_OK) return rc;
     if ((size_t)S * ix->dpad > ix->xh_tmp_cap) {   // (exact size: grow() would double a multi-GB buffer)
         if (ix->xh_tmp) CSS_HIP_TRY(hipFree(ix->xh_tmp));

@@ -1453,13 +1453,31 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
         __syncthreads();
         const int T = min(ex_n, CZ_EXK);
         const int lane_ = tid & 63, wave_ = tid >> 6;
-        for (int r = wave_; r < T; r += 4) {
-            const float* xr = ex_x + (size_t)ex_id[r] * ex_dpad;
-            const float* qr = ex_q + (size_t)q * ex_dpad;
-            float a_ = 0.f;
-            for (int c = lane_; c < ex_dpad; c += 64) a_ = fmaf(xr[c], qr[c], a_);
+        // (a wave per row, two rows in flight per wave; 16-byte loads: ex_dpad is a multiple of 256 on this path)
+        const int nv = ex_dpad >> 2;
+        const float4* qr = reinterpret_cast<const float4*>(ex_q + (size_t)q * ex_dpad);
+        for (int r = wave_; r < T; r += 8) {
+            const int r2 = r + 4 < T ? r + 4 : r;
+            const float4* xa = reinterpret_cast<const float4*>(ex_x + (size_t)ex_id[r] * ex_dpad);
+            const float4* xb2 = reinterpret_cast<const float4*>(ex_x + (size_t)ex_id[r2] * ex_dpad);
+            float a_ = 0.f, b_ = 0.f;
+            for (int c = lane_; c < nv; c += 64) {
+                const float4 xv = xa[c], yv = xb2[c], qv = qr[c];
+                a_ = fmaf(xv.x, qv.x, a_);
+                a_ = fmaf(xv.y, qv.y, a_);
+                a_ = fmaf(xv.z, qv.z, a_);
+                a_ = fmaf(xv.w, qv.w, a_);
+                b_ = fmaf(yv.x, qv.x, b_);
+                b_ = fmaf(yv.y, qv.y, b_);
+                b_ = fmaf(yv.z, qv.z, b_);
+                b_ = fmaf(yv.w, qv.w, b_);
+            }
             a_ = wave_allsum(a_);
-            if (lane_ == 0) ex_s[r] = a_;
+            b_ = wave_allsum(b_);
+            if (lane_ == 0) {
+                ex_s[r] = a_;
+                if (r2 != r) ex_s[r2] = b_;
+            }
         }
         __syncthreads();
         if (T >= k && tid < T) {   // rank by counting (T <= CZ_EXK entries)

@@ -15,8 +15,9 @@ cascade on every shard -> ONE RCCL all-gather of the packed per-shard top-k (nq*
 
 The JSON line also carries:
   roofline      dominant kernel of the timed region -- the main stage of the search cascade,
-                k_scan_coarse<false,true,..> (bf16 MFMA bound) -- measured with HIP events on the
-                launch stream inside this run (css_prof_*); `traffic` = HBM-side bytes per launch
+                k_scan_coarse8<false,true,..> on the int8 shadow rows (int8 MFMA peak; `frac_of_bf16_peak`
+                beside it; the bf16 scan where the library takes that) -- measured with HIP events on the
+                launch stream inside this run (css_prof_*); `traffic` = L2-miss (fabric-side) bytes per launch
                 from the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes).
                 Sub-objects (same fields): `nq1_k10` -- the single-query search, the reference's real call
                 shape, with the HBM roofline of its main sweep over the bytes that sweep reads (int8 rows + row
@@ -27,7 +28,8 @@ The JSON line also carries:
                 workload, rank 0 / N=1 only: blocked SGEMM + heap on all cores; `encode`: the torch oracle at
                 batch 16.
   extra         details: k'=100 single query, masked search, per-kernel encoder times, length-mix and
-                text-path (strings in) runs, flagged fraction on clustered rows.
+                text-path (strings in) runs, flagged fraction on clustered rows (1 M and 10 M), shadow-less index,
+                BASELINE configs[4]'s 80 M rows on one GPU (`single_gpu_80M`).
 """
 from __future__ import annotations
 

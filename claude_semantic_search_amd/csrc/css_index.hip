@@ -1797,7 +1797,7 @@ inline bool sweep_uses_i8(css_index* ix) {
 // exactly); 4096 queries, k = 10: 29.0 / 52.3.  CSS_KNN_SCAN=i8 / bf16 force one or the other.
 // Its wider band also flags more queries on clustered rows (10 M rows in 20 000 clusters: 23 % of the queries, 14.8 ms
 // against the bf16 scan's 13.3 with none flagged), so the choice adapts per index: when an int8 batch flagged more than
-// 2 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
+// 5 % of its queries the next 16 batches read the bf16 rows, then int8 is tried again.  (Caller holds ws_mu.)
 // (`rows`: the rows one cascade covers -- the index, or one range of a shadow-less index)
 inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     const KnnEnv& e = knn_env();
@@ -1806,7 +1806,9 @@ inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     if (e.batch_i8 == 2) return true;
     const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 4000000 && nq >= 256);
     if (!pays) return false;
-    return i8_feedback_allows(ix->fb_batch, 20);
+    // (with <= 256 flagged queries the second pass is one query tile of bf16 scan -- a quarter of a 1000-query bf16 step --
+    // and the int8 search still wins: 10 M rows in 20 000 clusters, 33 flagged: 12.8 ms against 13.3 on bf16 rows)
+    return i8_feedback_allows(ix->fb_batch, 50);
 }
 inline bool batch_uses_i8(css_index* ix, int k, int64_t nq) {
     if (ix->x8 == nullptr) return false;

@@ -91,6 +91,8 @@ def parse_args(argv=None):
     ap.add_argument("--only-encoder", action="store_true", help="development aid: run just the encoder leg")
     ap.add_argument("--enc-fixed-only", action="store_true", help="encoder leg: only the fixed batch x len shape (counter passes)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling line of the 10 M-row index")
+    ap.add_argument("--no-check", action="store_true", help="skip the self-check of the timed region's answers")
+    ap.add_argument("--allow-debug", action="store_true", help="print a line (marked invalid) although a *_DBG switch is set")
     return ap.parse_args(argv)
 
 
@@ -143,15 +145,12 @@ def cpu_baseline_knn(args, log):
         "cores": int(blas_threads),
         "kind": "port",
         "achieved_GFLOPs": gflops,
-        "sample": f"first {rows} of {args.rows} rows x {args.nq} queries, blocked SGEMM (numpy BLAS, {blas_threads} threads; "
-                  f"limited by that BLAS build, far below what these cores can do in SGEMM) "
-                  f"+ heap fold in C/OpenMP (oracle.knn_oracle.search_blas), time scaled x{args.rows / rows:.1f} (extrapolated)",
-        "nq1_single_thread": {
-            "value": 1.0 / full1, "unit": "queries/s", "cores": 1, "kind": "port", "latency_ms": full1 * 1e3, "k": 100,
-            "scan_GBps": rows1 * args.dim * 4 / t1 / 1e9,
-            "sample": f"one query, top-100 (the reference's k' for top_k = 10), first {rows1} of {args.rows} rows, scalar C scan on "
-                      f"1 thread (oracle.knn_oracle.FlatIndexOracle.search), mean of {reps1} queries, time scaled "
-                      f"x{args.rows / rows1:.1f} (extrapolated)"},
+        "sample": f"first {rows} of {args.rows} rows x {args.nq} q, numpy SGEMM + C heap fold, time x{args.rows / rows:.1f} (extrapolated)",
+        "blas_note": "numpy's BLAS build limits this (far below what these cores can do in SGEMM); oracle.knn_oracle.search_blas",
+        # the reference's real call shape: one query, k' = 100, one thread (faiss scans single queries on one thread)
+        "nq1_one_thread_latency_ms": full1 * 1e3,
+        "nq1_one_thread_scan_GBps": rows1 * args.dim * 4 / t1 / 1e9,
+        "nq1_sample": f"1 query top-100, scalar C scan on 1 thread, first {rows1} rows, mean of {reps1}, time x{args.rows / rows1:.1f}",
     }
 
 
@@ -359,8 +358,7 @@ def bench_encoder(args, dev, log):
         cos = (out[pick].cpu().numpy() * ref).sum(1)
         res["cpu_baseline"] = {"value": len(pick) / tc, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
                                "achieved_GFLOPs": encoder_flops([L] * len(pick)) / tc / 1e9,
-                               "sample": f"{len(pick)} of the {B} sequences (L={L}), batch 16, through "
-                                         f"oracle.mpnet_oracle.encode_batched (torch fp32, {torch.get_num_threads()} threads)"}
+                               "sample": f"{len(pick)} of {B} seqs (L={L}), batch 16, mpnet_oracle (torch fp32, {torch.get_num_threads()} thr)"}
         res["parity_vs_oracle_min_cos"] = float(cos.min())
         log(f"encoder cpu baseline: {len(pick)} seqs in {tc:.2f}s; min cos vs oracle {cos.min():.6f}")
     if args.enc_fixed_only:
@@ -493,6 +491,65 @@ def bench_encoder(args, dev, log):
     return res
 
 
+def env_overrides():
+    """Every CSS_* switch set in this process's environment ("NAME=value"): the shipped library honours them (DESIGN.md
+    6, "Environment switches"), so a bench line states which were in force."""
+    return sorted(f"{k_}={v}" for k_, v in os.environ.items() if k_.startswith("CSS_"))
+
+
+def self_launch(n: int, script: str, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N <script>
+    <same arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1), pass its stdout / stderr
+    through and return its exit status (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def check_answers(index, q_host, D, I, id_base, k, log, nq_check=256, n_rescore=16, sample_rows=100_000, require_local=True):
+    """Self-check of the answers the timed region produced, on this rank's shard (size-independent properties, the
+    ones tests/test_fullsize_gpu.py holds): fp64 re-score of `n_rescore` returned rows read back from the index, and
+    no row of a `sample_rows`-row sample of the shard beats a query's k-th returned score.  numpy on the host only."""
+    import numpy as np
+
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    nq = Dh.shape[0]
+    qn = q_host.astype(np.float64)
+    qn = qn / (np.linalg.norm(qn, axis=1, keepdims=True) + 1e-8)
+    n_local = index.ntotal
+    local = (Ih >= id_base) & (Ih < id_base + n_local)
+    worst, checked = 0.0, 0
+    for r in np.linspace(0, nq - 1, num=min(nq, 64)).astype(int):
+        for j in np.nonzero(local[r])[0]:
+            if checked >= n_rescore:
+                break
+            row = index.reconstruct(int(Ih[r, j] - id_base)).astype(np.float64)
+            worst = max(worst, abs(float(row @ qn[r]) - float(Dh[r, j])))
+            checked += 1
+    assert worst < 1e-3 and (checked > 0 or not require_local), f"fp64 re-score of returned rows differs by {worst} (checked {checked})"
+    m = min(sample_rows, n_local)
+    row0 = max(0, (n_local * 3 // 10) - m // 2)
+    sample = index.reconstruct_n(row0, m)
+    nqc = min(nq, nq_check)
+    best = (qn[:nqc].astype(np.float32) @ sample.T).max(axis=1)
+    in_sample = ((Ih[:nqc] >= id_base + row0) & (Ih[:nqc] < id_base + row0 + m)).any(axis=1)
+    viol = int((best[~in_sample] > Dh[:nqc][~in_sample, k - 1] + 1e-5).sum())
+    assert viol == 0, f"{viol} queries: a sampled row beats the k-th returned score"
+    log(f"self-check: fp64 re-score of {checked} returned rows within {worst:.1e}; {m}-row sample never beats the k-th "
+        f"score of {nqc} queries")
+    return {"rescored_rows": checked, "max_abs_diff_vs_fp64": worst, "sample_rows": int(m), "sample_queries": int(nqc),
+            "sample_violations": viol}
+
+
 def timed_steps(step, fence, nsteps):
     t0 = time.perf_counter()
     for _ in range(nsteps):
@@ -573,11 +630,22 @@ def _main(argv, platform_factory):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE anything in
+        # this process touches the GPU (no HIP call, no torch.cuda.* above this line); relay rank 0's JSON line and
+        # the ranks' exit status.  Under torch.distributed.run (WORLD_SIZE set) this branch is never taken.
+        sys.exit(self_launch(args.gpus, sys.argv[0], list(sys.argv[1:] if argv is None else argv)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
         raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    overrides = env_overrides()
+    debug_switches = [o for o in overrides if o.split("=")[0].endswith("_DBG") or o.startswith("CSS_BENCH_NOCHECK")]
+    if debug_switches and not args.allow_debug:
+        print(f"bench.py: {debug_switches} make the library return wrong results by design (timing ablations): no headline "
+              "is printed with them set (--allow-debug prints a line marked invalid)", file=sys.stderr)
+        sys.exit(2)
 
     def log(msg):
         if rank == 0:
@@ -647,6 +715,9 @@ def _main(argv, platform_factory):
     if world > 1:   # every shard contributes to the merged answer
         owners = torch.bincount((I.flatten() // args.rows).clamp_(max=world - 1), minlength=world)
         assert int((owners > 0).sum()) == world, owners.tolist()
+    self_check = None
+    if hip and not args.no_check:   # the answers of the timed region, checked on this rank's shard (not timed)
+        self_check = check_answers(index, q_host, D, I, index_id_base(sh), args.k, log, require_local=world == 1)
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
     kernels = {}
@@ -676,23 +747,18 @@ def _main(argv, platform_factory):
             sweep_bytes = main_rows * (args.dim + 4 if scan_i8 else args.dim * 2)   # shadow rows (int8 + scale / bf16) read once
             peak_ = INT8_MFMA_PEAK_TF if scan_i8 else BF16_MFMA_PEAK_TF
             roofline = {"bound": "mfma",
-                        "kernel": ("k_scan_coarse8<false,true,..,int8> (main stage of the cascade, int8 shadow rows)" if scan_i8
-                                   else "k_scan_coarse8<false,true> (main stage of the cascade)"),
+                        "kernel": ("k_scan_coarse8<false,true,false,4096,true> (cascade main stage, int8 rows)" if scan_i8
+                                   else "k_scan_coarse8<false,true,false,4096,false> (cascade main stage, bf16 rows)"),
                         "achieved": flops / avg_s / 1e12, "peak": peak_, "unit": "TFLOP/s",
                         "frac": flops / avg_s / 1e12 / peak_, "traffic": None,
                         "launches": n, "avg_ms": ms / n, "rows_per_launch": main_rows, "cascade_growth": g_,
                         "hbm_GBps": sweep_bytes / avg_s / 1e9,
-                        "arithmetic": ("int8 operands (shadow rows + int8 queries), exact int32 accumulate, v_mfma_i32_16x16x64_i8; "
-                                       "candidates inside the measured error band rescored in fp32") if scan_i8 else
-                                      ("bf16 operands (shadow rows), fp32 accumulate, v_mfma_f32_16x16x32_bf16; "
-                                       "candidates rescored in fp32"),
+                        "arithmetic": ("int8 x int8 -> exact int32 (v_mfma_i32_16x16x64_i8); band rows rescored in fp32" if scan_i8 else
+                                       "bf16 x bf16 -> fp32 (v_mfma_f32_16x16x32_bf16); band rows rescored in fp32"),
                         "frac_of_bf16_peak": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF,
                         "executed_mfma_TFLOPs": flops * (-(-args.nq // 256) * 256 / args.nq) / avg_s / 1e12}
             if scan_i8:
-                roofline["note"] = ("the 8-phase loop moves the same bytes per K step as the bf16 scan and takes the same time per "
-                                    "step (tools/gemm_lab.hip -DLAB_I8): it is bound by its LDS / DMA traffic and the package power, "
-                                    "so against the int8 MFMA peak the fraction is lower than the bf16 scan's against its peak "
-                                    "while the search is faster; CSS_KNN_SCAN=bf16 measures the bf16 scan")
+                roofline["note"] = "LDS-traffic / power bound loop; CSS_KNN_SCAN=bf16 measures the bf16 scan (DESIGN.md 3.1)"
             if "knn_coarse_cascade" in kernels:
                 cms, cn = kernels["knn_coarse_cascade"]
                 roofline["cascade_ms"] = cms / cn           # all stages + selects + rescoring of one search
@@ -759,8 +825,12 @@ def _main(argv, platform_factory):
                    "whole_call_frac_of_peak": shard * row_b / dt / 1e9 / HBM_PEAK_GBS,
                    "effective_fp32_index_GBps": shard * args.dim * 4 / dt / 1e9,
                    "rows_read_as": "int8 + per-row scale (bf16 rows would be twice the bytes)" if i8 else "bf16"}
-            if kq == 10 and roofline is not None:
-                roofline["nq1_k10"] = rec
+            if roofline is not None:   # flat scalars: the driver's parser keeps no nested objects (details: extra.nq1_k*)
+                roofline[f"nq1_k{kq}_latency_ms"] = rec["latency_ms"]
+                roofline[f"nq1_k{kq}_main_sweep_hbm_frac"] = rec["frac"]
+                roofline[f"nq1_k{kq}_main_sweep_GBps"] = rec["achieved"]
+                roofline[f"nq1_k{kq}_whole_call_hbm_frac"] = rec["whole_call_frac_of_peak"]
+                roofline[f"nq1_k{kq}_traffic_bytes"] = rec["traffic"]
             extra[f"nq1_k{kq}"] = rec
             nat.prof_reset()
 
@@ -769,7 +839,10 @@ def _main(argv, platform_factory):
             try:
                 extra["query_e2e"] = bench_query_e2e(args, dev, index, stream, log)
                 if roofline is not None:
-                    roofline["query_e2e"] = extra["query_e2e"]
+                    roofline["query_e2e_ms"] = extra["query_e2e"]["chained_ms"]
+                    roofline["query_e2e_encode_ms"] = extra["query_e2e"]["encode_ms"]
+                    roofline["query_e2e_search_ms"] = extra["query_e2e"]["search_ms"]
+                    roofline["query_e2e_host_api_ms"] = extra["query_e2e"]["host_api_chain_ms"]
             except Exception as ex_:   # an extra: never fail the bench line over it
                 extra["query_e2e"] = {"error": repr(ex_)}
 
@@ -838,7 +911,12 @@ def _main(argv, platform_factory):
             nat.prof_reset()
             extra["exact_fp32_mode"] = ex
             if roofline is not None:
-                roofline["exact_fp32_mode"] = ex
+                roofline["exact_fp32_nq1_hbm_frac"] = ex["nq1_k10"]["frac"]
+                roofline["exact_fp32_nq1_GBps"] = ex["nq1_k10"]["achieved"]
+                roofline["exact_fp32_nq1_latency_ms"] = ex["nq1_k10"]["latency_ms"]
+                roofline["exact_fp32_nq1_traffic_bytes"] = ex["nq1_k10"]["traffic"]
+                roofline[f"exact_fp32_nq{nqe}_mfma_frac"] = ex[f"nq{nqe}_k{args.k}"]["frac"]
+                roofline[f"exact_fp32_nq{nqe}_ms"] = ex[f"nq{nqe}_k{args.k}"]["ms_per_batch"]
         finally:
             index.set_search_mode("auto")
 
@@ -900,25 +978,32 @@ def _main(argv, platform_factory):
             enc["ms_per_batch_max_over_ranks"] = float(t[1].item())
             enc["parallelism"] = f"{world} replicas, no collective"
         extra["encode"] = enc
-        if roofline is not None:
-            er = dict(enc["roofline"])
-            er.update(chunks_per_s=enc.get("chunks_per_s_all_ranks", enc["chunks_per_s"]), ms_per_batch=enc["ms_per_batch"],
-                      batch=enc["batch"], seq_len=enc["seq_len"], algorithmic_TFLOP_per_batch=enc["algorithmic_TFLOP_per_batch"],
-                      length_mix_chunks_per_s=enc.get("length_mix", {}).get("chunks_per_s"),
-                      parity_vs_oracle_min_cos=enc.get("parity_vs_oracle_min_cos"))
-            roofline["encode"] = er
-        if cpu is not None and "cpu_baseline" in enc:
-            cpu["encode"] = enc["cpu_baseline"]
+        if roofline is not None:   # "chunks embedded/sec" of BASELINE's metric, as flat scalars (details: extra.encode)
+            roofline["encode_chunks_per_s"] = enc.get("chunks_per_s_all_ranks", enc["chunks_per_s"])
+            roofline["encode_ms_per_batch"] = enc["ms_per_batch"]
+            roofline["encode_frac"] = enc["roofline"]["frac"]
+            roofline["encode_TFLOPs"] = enc["roofline"]["achieved"]
+            roofline["encode_peak_TFLOPs"] = enc["roofline"]["peak"]
+            roofline["encode_batch"] = enc["batch"]
+            roofline["encode_seq_len"] = enc["seq_len"]
+            roofline["encode_traffic_bytes"] = enc["roofline"].get("traffic")
+            roofline["encode_length_mix_chunks_per_s"] = enc.get("length_mix", {}).get("chunks_per_s")
+            roofline["encode_min_cos_vs_oracle"] = enc.get("parity_vs_oracle_min_cos")
+            for kn_, kv_ in enc.get("kernels", {}).items():
+                if "TFLOPs" in kv_:
+                    roofline[f"{kn_}_ms"] = kv_["ms_per_batch"]
+                    roofline[f"{kn_}_frac"] = kv_["TFLOPs"] / BF16_MFMA_PEAK_TF
+        if cpu is not None and "cpu_baseline" in enc:   # flat scalars (details: extra.encode.cpu_baseline)
+            cpu["encode_chunks_per_s"] = enc["cpu_baseline"]["value"]
+            cpu["encode_cores"] = enc["cpu_baseline"]["cores"]
+            cpu["encode_sample"] = enc["cpu_baseline"]["sample"]
 
     if world > 1:
         plat.barrier()
     if rank == 0:
-        cfg_name = ("BASELINE configs[3]: 10Mx768 index on 1 MI355X, 1k-query batch top-10" if world == 1 and args.rows == 10_000_000
-                    else f"BASELINE configs[4] shape: {rows_total}x{args.dim} index sharded over {world} MI355X "
-                         f"({args.rows} rows per GPU), all-gather of per-shard top-k")
+        cfg_name = ("BASELINE configs[3]" if world == 1 and args.rows == 10_000_000 else "BASELINE configs[4] shape")
         out = {
-            "metric": f"queries/sec@top-{args.k} over Nx{args.dim} flat index ({args.nq}-query batch); "
-                      "chunks embedded/sec in roofline.encode",
+            "metric": f"queries/sec@top-{args.k} over Nx{args.dim} index (+ chunks embedded/sec: roofline.encode_chunks_per_s)",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -928,18 +1013,22 @@ def _main(argv, platform_factory):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (index, queries and returned scores fp32; candidate selection by an int8 MFMA scan -- bf16 for k > 128 and "
-                     "small shards -- inside a rigorous, measured error band, candidates rescored in fp32)",
+            "dtype": "f32 (int8/bf16 MFMA candidate scan in a measured error band + exact fp32 rescoring)",
             "data": "synthetic" if hip else f"synthetic, on the {plat.name} platform (control-flow rehearsal: NOT a measurement)",
-            "config": {"workload": f"{cfg_name}: {rows_total}x{args.dim} fp32 flat inner-product index, nq={args.nq}, "
-                                   f"top-{args.k}, {args.rows} rows per GPU",
+            "config": {"workload": f"nq={args.nq} k={args.k} {rows_total}x{args.dim} fp32 flat IP index, {world} GPU "
+                                   f"({args.rows} rows/GPU): {cfg_name}",
                        "rows_total": rows_total, "rows_per_gpu": shard, "dim": args.dim, "nq": args.nq, "k": args.k,
-                       "parallelism": f"row-shard x{world} + one packed all-gather(top-k) + merge (ShardedFlatIndex)",
+                       "parallelism": f"row-shard x{world} + one packed all-gather(top-k) + merge",
                        "strong_10M": strong},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "self_check": self_check,
+            "env_overrides": overrides,
             "extra": extra,
         }
+        if debug_switches:
+            out["invalid"] = f"debug switches set: {debug_switches}"
+            out["metric"] = "INVALID (debug switches) " + out["metric"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -994,7 +1083,37 @@ def bench_80m_one_gpu(args, dev, stream, log, n=80_000_000):
                 rec["fp32_sweep_GBps"] = n * args.dim * 4 / dt / 1e9
             out[f"nq{nq_}"] = rec
             nat.prof_reset()
-        log(f"80 M rows on one GPU: {out[f'nq{args.nq}']['ms']:.0f} ms per {args.nq} queries, {out['nq1']['ms']:.1f} ms per single query")
+        # parity of this configuration (rows beyond 2^26 of one add, several int8 scratch ranges, k_merge_parts with ids
+        # beyond 2^26): queries that ARE rows around 2^24 / 2^26 / 6e7 / the end must find themselves first with score 1,
+        # and the batched ranges path must agree with the exact fp32 kernels on a mixed batch.  Fails the extra if not.
+        import numpy as np
+
+        probe = np.array([(1 << 24) + 3, (1 << 26) - 1, (1 << 26) + 12_345, 60_000_001, n - 5], dtype=np.int64)
+        qrows = np.stack([ix.reconstruct(int(i)) for i in probe])
+        qmix = np.concatenate([qrows, synth.rows(19, args.dim, 5)]).astype(np.float32)       # 24 queries: the ranges path
+        qm = torch.from_numpy(qmix).to(dev)
+        nm = qmix.shape[0]
+
+        def run(nq_):
+            ix.search_dev(qm.data_ptr(), nq_, args.k, Dd.data_ptr(), Id.data_ptr(), stream, normalize=True)
+            torch.cuda.synchronize()
+            return Dd[:nq_].cpu().numpy().copy(), Id[:nq_].cpu().numpy().copy()
+
+        Db, Ib = run(nm)
+        ix.set_search_mode("exact_fp32")
+        try:
+            De, Ie = run(nm)
+        finally:
+            ix.set_search_mode("auto")
+        D1, I1 = run(1)
+        assert (Ib[:len(probe), 0] == probe).all() and np.abs(Db[:len(probe), 0] - 1).max() < 1e-5, (Ib[:len(probe), 0], probe)
+        assert int(I1[0, 0]) == int(probe[0]) and abs(float(D1[0, 0]) - 1) < 1e-5
+        assert np.abs(Db - De).max() < 1e-5 and (Ib == Ie).mean() > 0.97, (np.abs(Db - De).max(), (Ib == Ie).mean())
+        assert (np.diff(Db, axis=1) <= 0).all() and all(len(set(r.tolist())) == args.k for r in Ib)
+        out["check"] = {"probe_rows_found_first": True, "max_score_diff_vs_exact_fp32": float(np.abs(Db - De).max()),
+                        "id_agreement_with_exact_fp32": float((Ib == Ie).mean()), "queries": int(nm)}
+        log(f"80 M rows on one GPU: {out[f'nq{args.nq}']['ms']:.0f} ms per {args.nq} queries, {out['nq1']['ms']:.1f} ms per single "
+            f"query; probe rows beyond 2^26 found, ranges path == exact fp32 kernels on {nm} queries")
     finally:
         ix.close()
         torch.cuda.empty_cache()

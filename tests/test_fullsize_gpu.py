@@ -121,7 +121,7 @@ def test_1m_clustered_rows_every_mode_matches_the_cpu_oracle():
 
 
 # ---- the benchmark's own inputs at BASELINE configs[3], against the CPU oracle -----------------------------------
-NQ_BENCH, NQ_ORACLE = 1000, 24
+NQ_BENCH, NQ_ORACLE = 1000, 256
 
 
 @pytest.fixture(scope="module")

@@ -91,9 +91,21 @@ def parse_args(argv=None):
     ap.add_argument("--only-encoder", action="store_true", help="development aid: run just the encoder leg")
     ap.add_argument("--enc-fixed-only", action="store_true", help="encoder leg: only the fixed batch x len shape (counter passes)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling line of the 10 M-row index")
+    ap.add_argument("--legs", default="all", help="comma list of the extra legs to run: nq1,e2e,masked,exact,clustered,noshadow,"
+                                                   "80m,clustered10m (default all; profiling passes isolate one population per kernel)")
     ap.add_argument("--no-check", action="store_true", help="skip the self-check of the timed region's answers")
     ap.add_argument("--allow-debug", action="store_true", help="print a line (marked invalid) although a *_DBG switch is set")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    allowed = ("nq1", "e2e", "masked", "exact", "clustered", "noshadow", "80m", "clustered10m")
+    legs = set(allowed) if a.legs == "all" else {x for x in a.legs.split(",") if x and x != "none"}
+    if legs - set(allowed):
+        ap.error(f"--legs: unknown {sorted(legs - set(allowed))}; choose from {allowed}")
+    if a.no_extra:
+        legs = set()
+    if a.no_heavy_extra:
+        legs -= {"noshadow", "80m", "clustered10m"}
+    a.legs = legs
+    return a
 
 
 def cpu_baseline_knn(args, log):
@@ -540,7 +552,12 @@ def check_answers(index, q_host, D, I, id_base, k, log, nq_check=256, n_rescore=
     row0 = max(0, (n_local * 3 // 10) - m // 2)
     sample = index.reconstruct_n(row0, m)
     nqc = min(nq, nq_check)
-    best = (qn[:nqc].astype(np.float32) @ sample.T).max(axis=1)
+    try:   # (a bounded BLAS pool: the box's CPU share is far below os.cpu_count())
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=16):
+            best = (qn[:nqc].astype(np.float32) @ sample.T).max(axis=1)
+    except ImportError:
+        best = (qn[:nqc].astype(np.float32) @ sample.T).max(axis=1)
     in_sample = ((Ih[:nqc] >= id_base + row0) & (Ih[:nqc] < id_base + row0 + m)).any(axis=1)
     viol = int((best[~in_sample] > Dh[:nqc][~in_sample, k - 1] + 1e-5).sum())
     assert viol == 0, f"{viol} queries: a sampled row beats the k-th returned score"
@@ -715,9 +732,7 @@ def _main(argv, platform_factory):
     if world > 1:   # every shard contributes to the merged answer
         owners = torch.bincount((I.flatten() // args.rows).clamp_(max=world - 1), minlength=world)
         assert int((owners > 0).sum()) == world, owners.tolist()
-    self_check = None
-    if hip and not args.no_check:   # the answers of the timed region, checked on this rank's shard (not timed)
-        self_check = check_answers(index, q_host, D, I, index_id_base(sh), args.k, log, require_local=world == 1)
+    D_timed, I_timed = D.clone(), I.clone()   # (checked after the latency legs below: see check_answers)
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
     kernels = {}
@@ -784,10 +799,10 @@ def _main(argv, platform_factory):
     extra = {}
     D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
     I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
-    if not args.no_extra and hip:
+    if args.legs and hip:
         D1 = torch.empty((1, 100), dtype=torch.float32, device=dev)
         I1 = torch.empty((1, 100), dtype=torch.int64, device=dev)
-        for kq, Dq, Iq in ((10, D[:1], I[:1]), (100, D1, I1)):
+        for kq, Dq, Iq in (((10, D[:1], I[:1]), (100, D1, I1)) if "nq1" in args.legs else ()):
             for _ in range(3):
                 index.search_dev(q.data_ptr(), 1, kq, Dq.data_ptr(), Iq.data_ptr(), stream, normalize=True)
             fence()
@@ -835,7 +850,7 @@ def _main(argv, platform_factory):
             nat.prof_reset()
 
         # ---- the reference's user-visible query: encode one query + search it (k' = 100) ----
-        if world == 1 and not args.no_encoder:
+        if world == 1 and not args.no_encoder and "e2e" in args.legs:
             try:
                 extra["query_e2e"] = bench_query_e2e(args, dev, index, stream, log)
                 if roofline is not None:
@@ -850,7 +865,7 @@ def _main(argv, platform_factory):
         words = (shard + 31) // 32
         mbits = torch.full((words,), 0x55555555, dtype=torch.int32, device=dev)   # every other row
         mk = {}
-        for nqm, reps in ((1, 10), (args.nq, 3)):
+        for nqm, reps in (((1, 10), (args.nq, 3)) if "masked" in args.legs else ()):
             for _ in range(2):
                 index.search_dev(q.data_ptr(), nqm, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True,
                                  allow_bits_ptr=mbits.data_ptr())
@@ -863,62 +878,72 @@ def _main(argv, platform_factory):
             dt = (time.perf_counter() - t0) / reps
             assert bool(((I[:nqm] - index_id_base(sh)) % 2 == 0).all())
             mk[f"nq{nqm}_k{args.k}"] = {"ms": dt * 1e3, "queries_per_s": nqm / dt}
-        extra["masked_half_rows"] = mk
+        if mk:
+            extra["masked_half_rows"] = mk
         del mbits
 
         # ---- the parity mode: every score formed by fp32 fmaf chains inside the scan kernels ----
-        index.set_search_mode("exact_fp32")
-        try:
-            ex = {}
-            for _ in range(2):
-                index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
-            fence()
-            nat.prof_reset()
-            nat.prof_enable(True)
-            t0 = time.perf_counter()
-            for _ in range(10):
-                index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
-            fence()
-            dt = (time.perf_counter() - t0) / 10
-            nat.prof_enable(False)
-            ms, n = nat.prof_read("knn_scan_small")
-            gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
-            tr = pmc_traffic("k_scan_small<1,", wl)
-            ex["nq1_k10"] = {"bound": "hbm", "kernel": "k_scan_small<1,12,IP> (fp32 VALU sweep)", "achieved": gbs,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
-                             "traffic": tr["bytes_per_launch"] if tr else None,
-                             "algorithmic_bytes_per_launch": shard * args.dim * 4,
-                             "latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
-            nat.prof_reset()
-            nqe = min(args.nq, 256)   # the fp32-input MFMA scan is 16x slower per flop than bf16: a quarter batch
-            index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
-            fence()
-            nat.prof_enable(True)
-            t0 = time.perf_counter()
-            index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
-            fence()
-            dt = time.perf_counter() - t0
-            nat.prof_enable(False)
-            ms, n = nat.prof_read("knn_scan_mfma")
-            fl = 2.0 * shard * args.dim * nqe
-            tr = pmc_traffic("k_scan_mfma<", wl)
-            ex[f"nq{nqe}_k{args.k}"] = {
-                "bound": "mfma", "kernel": "k_scan_mfma<IP> (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chains)",
-                "achieved": fl / (ms / n / 1e3) / 1e12 if n else None, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": fl / (ms / n / 1e3) / 1e12 / FP32_MFMA_PEAK_TF if n else None,
-                "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": shard * args.dim * 4,
-                "queries_per_s": nqe / dt, "ms_per_batch": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
-            nat.prof_reset()
-            extra["exact_fp32_mode"] = ex
-            if roofline is not None:
-                roofline["exact_fp32_nq1_hbm_frac"] = ex["nq1_k10"]["frac"]
-                roofline["exact_fp32_nq1_GBps"] = ex["nq1_k10"]["achieved"]
-                roofline["exact_fp32_nq1_latency_ms"] = ex["nq1_k10"]["latency_ms"]
-                roofline["exact_fp32_nq1_traffic_bytes"] = ex["nq1_k10"]["traffic"]
-                roofline[f"exact_fp32_nq{nqe}_mfma_frac"] = ex[f"nq{nqe}_k{args.k}"]["frac"]
-                roofline[f"exact_fp32_nq{nqe}_ms"] = ex[f"nq{nqe}_k{args.k}"]["ms_per_batch"]
-        finally:
-            index.set_search_mode("auto")
+        if "exact" in args.legs:
+            index.set_search_mode("exact_fp32")
+            try:
+                ex = {}
+                for _ in range(2):
+                    index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+                fence()
+                nat.prof_reset()
+                nat.prof_enable(True)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    index.search_dev(q.data_ptr(), 1, 10, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+                fence()
+                dt = (time.perf_counter() - t0) / 10
+                nat.prof_enable(False)
+                ms, n = nat.prof_read("knn_scan_small")
+                gbs = shard * args.dim * 4 / (ms / n / 1e3) / 1e9 if n else None
+                tr = pmc_traffic("k_scan_small<1,", wl)
+                ex["nq1_k10"] = {"bound": "hbm", "kernel": "k_scan_small<1,12,IP> (fp32 VALU sweep)", "achieved": gbs,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                                 "traffic": tr["bytes_per_launch"] if tr else None,
+                                 "algorithmic_bytes_per_launch": shard * args.dim * 4,
+                                 "latency_ms": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
+                nat.prof_reset()
+                nqe = min(args.nq, 256)   # the fp32-input MFMA scan is 16x slower per flop than bf16: a quarter batch
+                index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+                fence()
+                nat.prof_enable(True)
+                t0 = time.perf_counter()
+                index.search_dev(q.data_ptr(), nqe, args.k, D.data_ptr(), I.data_ptr(), stream, normalize=True)
+                fence()
+                dt = time.perf_counter() - t0
+                nat.prof_enable(False)
+                ms, n = nat.prof_read("knn_scan_mfma")
+                fl = 2.0 * shard * args.dim * nqe
+                tr = pmc_traffic("k_scan_mfma<", wl)
+                ex[f"nq{nqe}_k{args.k}"] = {
+                    "bound": "mfma", "kernel": "k_scan_mfma<IP> (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chains)",
+                    "achieved": fl / (ms / n / 1e3) / 1e12 if n else None, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": fl / (ms / n / 1e3) / 1e12 / FP32_MFMA_PEAK_TF if n else None,
+                    "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": shard * args.dim * 4,
+                    "queries_per_s": nqe / dt, "ms_per_batch": dt * 1e3, "scan_kernel_ms": ms / n if n else None}
+                nat.prof_reset()
+                extra["exact_fp32_mode"] = ex
+                if roofline is not None:
+                    roofline["exact_fp32_nq1_hbm_frac"] = ex["nq1_k10"]["frac"]
+                    roofline["exact_fp32_nq1_GBps"] = ex["nq1_k10"]["achieved"]
+                    roofline["exact_fp32_nq1_latency_ms"] = ex["nq1_k10"]["latency_ms"]
+                    roofline["exact_fp32_nq1_traffic_bytes"] = ex["nq1_k10"]["traffic"]
+                    roofline[f"exact_fp32_nq{nqe}_mfma_frac"] = ex[f"nq{nqe}_k{args.k}"]["frac"]
+                    roofline[f"exact_fp32_nq{nqe}_ms"] = ex[f"nq{nqe}_k{args.k}"]["ms_per_batch"]
+            finally:
+                index.set_search_mode("auto")
+
+    # ---- self-check of the timed region's answers on this rank's shard (not timed).  It runs AFTER the single-query
+    # latency legs: its host-side SGEMM leaves numpy's BLAS threads spinning on the box's few CPUs for tens of ms, which
+    # the next leg would measure as launch latency (seen: 4.7 ms instead of 1.5 ms per single query)
+    self_check = None
+    if hip and not args.no_check:
+        self_check = check_answers(index, q_host, D_timed, I_timed, index_id_base(sh), args.k, log, require_local=world == 1)
+    del D_timed, I_timed
 
     # ---- N > 1: strong scaling of the fixed args.rows-row index on the same ranks ----
     strong = None
@@ -940,22 +965,25 @@ def _main(argv, platform_factory):
         cpu = cpu_baseline_knn(args, log)
 
     # ---- clustered rows: how much of the throughput survives dense candidate bands (flagged fraction) ----
-    if world == 1 and not args.no_extra and hip:
-        try:
-            extra["clustered_1M"] = bench_clustered(args, dev, stream, log)
-        except Exception as ex_:   # an extra: never fail the bench line over it
-            extra["clustered_1M"] = {"error": repr(ex_)}
-        if args.rows >= 10_000_000 and not args.no_heavy_extra:
+    if world == 1 and args.legs and hip:
+        if "clustered" in args.legs:
+            try:
+                extra["clustered_1M"] = bench_clustered(args, dev, stream, log)
+            except Exception as ex_:   # an extra: never fail the bench line over it
+                extra["clustered_1M"] = {"error": repr(ex_)}
+        if args.rows >= 10_000_000 and args.legs & {"noshadow", "80m", "clustered10m"}:
             index.close()   # (46 GB back before three more 10 M-row indexes are built, one at a time)
-            try:   # an index without bf16 shadow rows (what a > 38 M-row shard gets): ranges of on-the-fly bf16 rows vs the split-operand scan
-                extra["no_shadow_10M"] = bench_no_shadow(args, dev, stream, log)
-            except Exception as ex_:
-                extra["no_shadow_10M"] = {"error": repr(ex_)}
-            try:   # SURVEY 8(d) config 5 on ONE GPU: 80 M x 768 = 245.8 GB of fp32 rows, no room for any shadow copy
-                extra["single_gpu_80M"] = bench_80m_one_gpu(args, dev, stream, log)
-            except Exception as ex_:
-                extra["single_gpu_80M"] = {"error": repr(ex_)}
-            for nc_ in (20000, 2000):   # 500 and 5000 rows per cluster: a band fits the cascade's buffers / only the second pass's
+            if "noshadow" in args.legs:
+                try:   # an index without bf16 shadow rows (what a > 38 M-row shard gets): ranges of on-the-fly bf16 rows vs the split-operand scan
+                    extra["no_shadow_10M"] = bench_no_shadow(args, dev, stream, log)
+                except Exception as ex_:
+                    extra["no_shadow_10M"] = {"error": repr(ex_)}
+            if "80m" in args.legs:
+                try:   # SURVEY 8(d) config 5 on ONE GPU: 80 M x 768 = 245.8 GB of fp32 rows, no room for any shadow copy
+                    extra["single_gpu_80M"] = bench_80m_one_gpu(args, dev, stream, log)
+                except Exception as ex_:
+                    extra["single_gpu_80M"] = {"error": repr(ex_)}
+            for nc_ in ((20000, 2000) if "clustered10m" in args.legs else ()):   # 500 and 5000 rows per cluster: a band fits the cascade's buffers / only the second pass's
                 try:
                     extra[f"clustered_10M_{nc_}_clusters"] = bench_clustered(args, dev, stream, log, n=10_000_000, nc=nc_,
                                                                              with_uniform=False)

@@ -24,7 +24,7 @@ CSS_ERR_OOM = -4
 CSS_ERR_STATE = -5
 METRIC_IP = 0
 METRIC_L2 = 1
-MAX_K = 128
+MAX_K = 2048   # include/css_hip.h CSS_MAX_K
 
 
 class CssError(RuntimeError):

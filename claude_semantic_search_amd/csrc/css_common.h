@@ -11,6 +11,10 @@
 
 #include "../../include/css_hip.h"
 
+// largest k ONE pass of the scan kernels serves (LDS lists, wave_insert: two slots per lane); css_index_search serves
+// k up to CSS_MAX_K by passes of this size (css_index.hip, search_any_k)
+#define CSS_KERNEL_MAX_K 128
+
 namespace css {
 
 void set_error(const char* fmt, ...);

@@ -55,6 +55,7 @@ struct css_index {
     int search_mode = CSS_SEARCH_AUTO;
     const uint32_t* cur_mask = nullptr;  // allow-bitmap of the search in progress (set under ws_mu)
     uint32_t* mask_ws = nullptr;   size_t mask_ws_cap = 0;   // device copy of a host bitmap
+    uint32_t* excl_ws = nullptr;   size_t excl_ws_cap = 0;   // k > 128: allow-bitmap minus the rows earlier passes returned
     int* maxn2 = nullptr;          // device, 3 words: bits of max ||row||^2, max ||row - bf16(row)||^2, max ||row - int8(row)||^2 (cz_eps)
     // int8 shadow rows (kept next to the bf16 ones when there is room): signed byte = round(x / s), s = max|x| / 127 per
     // row; read by the 1..4-query sweep and by the int8 MFMA scan of batches
@@ -1069,8 +1070,8 @@ __global__ __launch_bounds__(256) void k_merge_final(const float* __restrict__ p
                                                      int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
                                                      int l2_expanded, float* __restrict__ cs_out,
                                                      uint32_t* __restrict__ ci_out, int* __restrict__ cn_out) {
-    __shared__ float fs[CSS_MAX_K];
-    __shared__ uint32_t fi[CSS_MAX_K];
+    __shared__ float fs[CSS_KERNEL_MAX_K];
+    __shared__ uint32_t fi[CSS_KERNEL_MAX_K];
     __shared__ float cs[kMergeCap];
     __shared__ uint32_t ci[kMergeCap];
     __shared__ int cnt;
@@ -1209,8 +1210,8 @@ template <int METRIC>
 __global__ __launch_bounds__(64) void k_merge_parts(const float* __restrict__ Dp, const int64_t* __restrict__ Ip,
                                                     int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
                                                     float* __restrict__ D, int64_t* __restrict__ I) {
-    __shared__ float fs[CSS_MAX_K];
-    __shared__ int64_t fi[CSS_MAX_K];
+    __shared__ float fs[CSS_KERNEL_MAX_K];
+    __shared__ int64_t fi[CSS_KERNEL_MAX_K];
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
     for (int i = lane; i < k; i += 64) {
@@ -1232,6 +1233,102 @@ __global__ __launch_bounds__(64) void k_merge_parts(const float* __restrict__ Dp
         float s = fs[i];
         D[q * k + i] = METRIC == CSS_METRIC_IP ? (empty ? -FLT_MAX : s) : (empty ? FLT_MAX : -s);
         I[q * k + i] = empty ? -1 : id;
+    }
+}
+
+// ---- k beyond CSS_KERNEL_MAX_K (the reference passes k' = min(max_results, ntotal) for any max_results,
+// src/storage.py:432): passes of up to CSS_KERNEL_MAX_K results per query, every pass over the rows the earlier
+// passes did not return (an exclusion bitmap ANDed with the caller's allow-bitmap), then one sort of the k results.
+__global__ void k_mask_init(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int64_t words) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) dst[i] = src ? src[i] : 0xFFFFFFFFu;
+}
+__global__ void k_mask_clear(uint32_t* __restrict__ mask, const int64_t* __restrict__ I, int n, int64_t id_base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = I[i] - id_base;
+    if (I[i] >= 0 && r >= 0) atomicAnd(&mask[r >> 5], ~(1u << (r & 31)));
+}
+// one block per query: bitonic sort of its k (score, id) pairs by (score better first, lower id first; pads last)
+template <int METRIC>
+__global__ __launch_bounds__(1024) void k_sort_rows(float* __restrict__ D, int64_t* __restrict__ I, int k) {
+    __shared__ float ss[CSS_MAX_K];
+    __shared__ int64_t si[CSS_MAX_K];
+    float* Dq = D + (size_t)blockIdx.x * k;
+    int64_t* Iq = I + (size_t)blockIdx.x * k;
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const bool real = i < k && Iq[i] >= 0;
+        const float d = real ? Dq[i] : 0.f;
+        ss[i] = real ? (METRIC == CSS_METRIC_IP ? d : -d) : -INFINITY;   // larger = better
+        si[i] = real ? Iq[i] : INT64_MAX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < n2 / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;   // this sub-sequence sorts best-first
+                const float a = ss[lo], b = ss[hi];
+                const int64_t ia = si[lo], ib = si[hi];
+                const bool b_better = b > a || (b == a && ib < ia);
+                if (b_better == up) {
+                    ss[lo] = b; ss[hi] = a;
+                    si[lo] = ib; si[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const bool empty = si[i] == INT64_MAX;
+        Dq[i] = empty ? (METRIC == CSS_METRIC_IP ? -FLT_MAX : FLT_MAX) : (METRIC == CSS_METRIC_IP ? ss[i] : -ss[i]);
+        Iq[i] = empty ? -1 : si[i];
+    }
+}
+
+// The same merge for k beyond CSS_KERNEL_MAX_K (wave_insert holds two list slots per lane): every part is a list sorted
+// by the total order (score better first, then lower id), ids are unique over the parts, so the final rank of entry j
+// of part p is j + the number of entries of the other parts that precede it -- one binary search per other part.
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_merge_parts_rank(const float* __restrict__ Dp, const int64_t* __restrict__ Ip,
+                                                         int nparts, int64_t stride_d, int64_t stride_i, int64_t nq, int k,
+                                                         float* __restrict__ D, int64_t* __restrict__ I) {
+    const int64_t q = blockIdx.x;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        D[q * k + i] = METRIC == CSS_METRIC_IP ? -FLT_MAX : FLT_MAX;
+        I[q * k + i] = -1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nparts * k; e += blockDim.x) {
+        const int p = e / k, j = e - p * k;
+        const size_t o = (size_t)q * k + j;
+        const int64_t id = Ip[(size_t)p * stride_i + o];
+        if (id < 0) continue;
+        const float d = Dp[(size_t)p * stride_d + o];
+        const float sc = METRIC == CSS_METRIC_IP ? d : -d;
+        int rank = j;
+        for (int p2 = 0; p2 < nparts && rank < k; ++p2) {
+            if (p2 == p) continue;
+            const float* D2 = Dp + (size_t)p2 * stride_d + (size_t)q * k;
+            const int64_t* I2 = Ip + (size_t)p2 * stride_i + (size_t)q * k;
+            int lo = 0, hi = k;   // first position of part p2 that does NOT precede (sc, id); pads precede nothing
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int64_t id2 = I2[mid];
+                const float d2 = D2[mid];
+                const float s2 = METRIC == CSS_METRIC_IP ? d2 : -d2;
+                const bool precedes = id2 >= 0 && better<int64_t>(s2, id2, sc, id);
+                if (precedes) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            D[q * k + rank] = d;
+            I[q * k + rank] = id;
+        }
     }
 }
 
@@ -2122,6 +2219,16 @@ int merge_parts(const float* Dp, const int64_t* Ip, int nparts, int64_t stride_d
     DeviceGuard g(device);
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps("knn_merge_parts", st);
+    if (k > CSS_KERNEL_MAX_K) {
+        if (metric == CSS_METRIC_IP)
+            hipLaunchKernelGGL(k_merge_parts_rank<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(256), 0, st, Dp, Ip, nparts, stride_d,
+                               stride_i, nq, k, D, I);
+        else
+            hipLaunchKernelGGL(k_merge_parts_rank<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(256), 0, st, Dp, Ip, nparts, stride_d,
+                               stride_i, nq, k, D, I);
+        CSS_LAUNCH_CHECK();
+        return CSS_OK;
+    }
     if (metric == CSS_METRIC_IP)
         hipLaunchKernelGGL(k_merge_parts<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(64), 0, st, Dp, Ip, nparts, stride_d,
                            stride_i, nq, k, D, I);
@@ -2268,6 +2375,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
         CSS_LAUNCH_CHECK();
         return CSS_OK;
     }
+    CSS_REQUIRE(k <= CSS_KERNEL_MAX_K, "css_index_search: internal: k=%d reached the scan kernels (limit %d)", k, CSS_KERNEL_MAX_K);
     SweepGeom sg;
     if ((rc = make_sweep_geom(ix, k, &sg)) != CSS_OK) return rc;
 
@@ -2385,7 +2493,7 @@ int css_index_free(css_index* ix) {
         }
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->excl_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
                     ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->x8s_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
@@ -2623,6 +2731,51 @@ struct MaskScope {
     MaskScope(css_index* i, const uint32_t* m) : ix(i) { ix->cur_mask = m; }
     ~MaskScope() { ix->cur_mask = nullptr; }
 };
+
+// Any k in [1, CSS_MAX_K].  Up to CSS_KERNEL_MAX_K: one search.  Beyond: per query, ceil(k / CSS_KERNEL_MAX_K) passes of
+// the SAME search paths, pass p over the allowed rows the passes before it did not return (exclusion bitmap), its
+// results written straight into columns [p * 128, ..) of the query's output row; the comparator is total (score, then
+// id), so the concatenation is the exact top-k, and one final sort puts entries whose scores came from different
+// summation orders (fix-up sweep vs rescoring: <= 1e-6 apart) in order.  Everything is enqueued on `st`; nothing
+// waits for the device.  Caller holds ws_mu and a shared lock on mu.
+int search_any_k(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, const uint32_t* allow_dev,
+                 float* D_dev, int64_t* I_dev, hipStream_t st) {
+    CSS_REQUIRE(k >= 1 && k <= CSS_MAX_K, "css_index_search: k=%d outside [1, %d]", k, CSS_MAX_K);
+    if (k <= CSS_KERNEL_MAX_K || ix->ntotal == 0 || nq == 0) {
+        MaskScope ms(ix, allow_dev);
+        return search_dev_locked(ix, q_dev, nq, k, normalize_q, D_dev, I_dev, st);
+    }
+    CSS_REQUIRE(nq < (1 << 24), "css_index_search: nq=%lld out of range", (long long)nq);
+    int rc;
+    const int64_t words = (ix->ntotal + 31) / 32;
+    if (ix->ws_pending && ix->ws_stream != st) CSS_HIP_TRY(hipStreamWaitEvent(st, ix->ws_ev, 0));   // excl_ws is a shared workspace
+    if ((rc = grow(&ix->excl_ws, &ix->excl_ws_cap, (size_t)words)) != CSS_OK) return rc;
+    for (int64_t q = 0; q < nq; ++q) {
+        hipLaunchKernelGGL(k_mask_init, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->excl_ws, allow_dev, words);
+        CSS_LAUNCH_CHECK();
+        for (int p = 0; p < k; p += CSS_KERNEL_MAX_K) {
+            const int kk = std::min(CSS_KERNEL_MAX_K, k - p);
+            float* Dq = D_dev + (size_t)q * k + p;
+            int64_t* Iq = I_dev + (size_t)q * k + p;
+            {
+                MaskScope ms(ix, ix->excl_ws);
+                if ((rc = search_dev_locked(ix, q_dev + (size_t)q * ix->dim, 1, kk, normalize_q, Dq, Iq, st)) != CSS_OK) return rc;
+            }
+            if (p + kk < k) {
+                hipLaunchKernelGGL(k_mask_clear, dim3(1), dim3(CSS_KERNEL_MAX_K), 0, st, ix->excl_ws, (const int64_t*)Iq, kk, ix->id_base);
+                CSS_LAUNCH_CHECK();
+            }
+        }
+    }
+    if (ix->metric == CSS_METRIC_IP) hipLaunchKernelGGL(k_sort_rows<CSS_METRIC_IP>, dim3((unsigned)nq), dim3(1024), 0, st, D_dev, I_dev, k);
+    else hipLaunchKernelGGL(k_sort_rows<CSS_METRIC_L2>, dim3((unsigned)nq), dim3(1024), 0, st, D_dev, I_dev, k);
+    CSS_LAUNCH_CHECK();
+    if (hipEventRecord(ix->ws_ev, st) == hipSuccess) {   // (the exclusion bitmap is in use until here)
+        ix->ws_stream = st;
+        ix->ws_pending = true;
+    }
+    return CSS_OK;
+}
 }  // namespace
 
 int css_index_search_masked_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q,
@@ -2632,8 +2785,7 @@ int css_index_search_masked_dev(css_index* ix, const float* q_dev, int64_t nq, i
     std::shared_lock<std::shared_mutex> lk(ix->mu);
     std::lock_guard<std::mutex> wl(ix->ws_mu);
     DeviceGuard g(ix->device);
-    MaskScope ms(ix, allow_bits_dev);
-    return search_dev_locked(ix, q_dev, nq, k, normalize_q, D_dev, I_dev, (hipStream_t)stream);
+    return search_any_k(ix, q_dev, nq, k, normalize_q, allow_bits_dev, D_dev, I_dev, (hipStream_t)stream);
 }
 
 int css_index_search_dev(css_index* ix, const float* q_dev, int64_t nq, int k, int normalize_q, float* D_dev,
@@ -2673,9 +2825,8 @@ int css_index_search_masked(css_index* ix, const float* q_host, int64_t nq, int 
         CSS_HIP_TRY(hipMemcpyAsync(ix->mask_ws, allow_bits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
         mask_dev = ix->mask_ws;
     }
-    MaskScope ms(ix, mask_dev);
     CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, q_host, (size_t)nq * ix->dim * 4, hipMemcpyHostToDevice, ix->stream));
-    if ((rc = search_dev_locked(ix, ix->q_raw, nq, k, normalize_q, ix->out_d, ix->out_i, ix->stream)) != CSS_OK)
+    if ((rc = search_any_k(ix, ix->q_raw, nq, k, normalize_q, mask_dev, ix->out_d, ix->out_i, ix->stream)) != CSS_OK)
         return rc;
     CSS_HIP_TRY(hipMemcpyAsync(D_host, ix->out_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
     CSS_HIP_TRY(hipMemcpyAsync(I_host, ix->out_i, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ix->stream));

@@ -265,40 +265,60 @@ def write_index(index: IndexFlat, path: str, chunk_rows: int = 1 << 18) -> None:
             f.write(index.reconstruct_n(r0, m).tobytes())
 
 
+def _need(f, nbytes: int, what: str) -> bytes:
+    buf = f.read(nbytes)
+    if len(buf) != nbytes:
+        raise RuntimeError(f"truncated index file (in {what})")
+    return buf
+
+
+def _read_header(f):
+    """Header of an IndexFlat file -> (d, ntotal, metric).  Anything but a self-consistent flat index raises."""
+    fourcc = _need(f, 4, "fourcc")
+    if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
+        raise RuntimeError(f"unsupported index file (fourcc {fourcc!r}); only IndexFlat (IxFI / IxF2 / IxFl) is implemented")
+    (d,) = struct.unpack("<i", _need(f, 4, "d"))
+    (n,) = struct.unpack("<q", _need(f, 8, "ntotal"))
+    _need(f, 16, "header")                                   # two dummies (1 << 20 each): not interpreted, as in faiss
+    (trained,) = struct.unpack("<B", _need(f, 1, "is_trained"))
+    (mtype,) = struct.unpack("<i", _need(f, 4, "metric_type"))
+    if mtype not in (0, 1):
+        raise RuntimeError(f"unsupported metric_type {mtype} in index file (0 = inner product, 1 = L2)")
+    metric = METRIC_INNER_PRODUCT if mtype == 0 else METRIC_L2
+    if fourcc != b"IxFl" and fourcc != _FOURCC[metric]:
+        raise RuntimeError(f"corrupt index file: fourcc {fourcc!r} with metric_type {mtype}")
+    if trained != 1:
+        raise RuntimeError("corrupt index file: a flat index is always trained")
+    (nfl,) = struct.unpack("<Q", _need(f, 8, "vector size"))
+    if d <= 0 or n < 0 or nfl != n * d:
+        raise RuntimeError(f"corrupt index file: d={d}, ntotal={n}, {nfl} floats")
+    return d, n, metric
+
+
+def read_index_header(path: str):
+    """``(d, ntotal, metric, byte offset of the rows)`` of an IndexFlat file whose payload is complete (a sharded
+    reader then takes its own block of the rows: ``sharded.read_index_sharded``)."""
+    import os
+
+    with open(path, "rb") as f:
+        d, n, metric = _read_header(f)
+        offset = f.tell()
+    if os.path.getsize(path) < offset + n * d * 4:
+        raise RuntimeError("truncated index file (in rows)")
+    return d, n, metric, offset
+
+
 def read_index(path: str, device: int = 0, chunk_rows: int = 1 << 18) -> IndexFlat:
     """``faiss.read_index`` for the flat indexes the reference writes (``src/storage.py:301-316``, ``:870-885``).
     Anything else -- another index family, an untrained index, a header that contradicts itself, a file shorter
     than its header promises -- raises ``RuntimeError`` (the reference then starts a fresh index, ``:314-316``)."""
-    def need(f, nbytes: int, what: str) -> bytes:
-        buf = f.read(nbytes)
-        if len(buf) != nbytes:
-            raise RuntimeError(f"truncated index file (in {what})")
-        return buf
-
     with open(path, "rb") as f:
-        fourcc = need(f, 4, "fourcc")
-        if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
-            raise RuntimeError(f"unsupported index file (fourcc {fourcc!r}); only IndexFlat (IxFI / IxF2 / IxFl) is implemented")
-        (d,) = struct.unpack("<i", need(f, 4, "d"))
-        (n,) = struct.unpack("<q", need(f, 8, "ntotal"))
-        need(f, 16, "header")                                   # two dummies (1 << 20 each): not interpreted, as in faiss
-        (trained,) = struct.unpack("<B", need(f, 1, "is_trained"))
-        (mtype,) = struct.unpack("<i", need(f, 4, "metric_type"))
-        if mtype not in (0, 1):
-            raise RuntimeError(f"unsupported metric_type {mtype} in index file (0 = inner product, 1 = L2)")
-        metric = METRIC_INNER_PRODUCT if mtype == 0 else METRIC_L2
-        if fourcc != b"IxFl" and fourcc != _FOURCC[metric]:
-            raise RuntimeError(f"corrupt index file: fourcc {fourcc!r} with metric_type {mtype}")
-        if trained != 1:
-            raise RuntimeError("corrupt index file: a flat index is always trained")
-        (nfl,) = struct.unpack("<Q", need(f, 8, "vector size"))
-        if d <= 0 or n < 0 or nfl != n * d:
-            raise RuntimeError(f"corrupt index file: d={d}, ntotal={n}, {nfl} floats")
+        d, n, metric = _read_header(f)
         index = IndexFlat(d, metric, device)
         if n:
             index.reserve(n)
         for r0 in range(0, n, chunk_rows):
             m = min(chunk_rows, n - r0)
-            buf = need(f, m * d * 4, "rows")
+            buf = _need(f, m * d * 4, "rows")
             index.add(np.frombuffer(buf, dtype=np.float32).reshape(m, d))
     return index

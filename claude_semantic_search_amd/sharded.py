@@ -71,6 +71,7 @@ class ShardedFlatIndex:
         self.shard_sizes = [0] * self.world          # replicated bookkeeping (all adds are collective calls)
         self.segments: List[Tuple[int, int, int]] = []   # (local_row0, global_row0, n) of THIS shard
         self._seg_tensors = None
+        self._dead: Optional[np.ndarray] = None          # tombstones in global numbering (replicated; mark_deleted)
 
     # -- building ----------------------------------------------------------
     def _append_segment(self, n_local: int, global_row0: int) -> None:
@@ -155,8 +156,48 @@ class ShardedFlatIndex:
                                                       ctypes.c_void_p(st)))
         return Dm, Im
 
-    def search_tensors(self, q, k: int, normalize: bool = False):
-        """``q``: [nq, d] float32 tensor on this rank's device (same on all ranks).
+    # -- allow-masks and tombstones (filter push-down, src/storage.py:438-492, :611-635) --------------------
+    def local_rows_of(self, global_mask: np.ndarray) -> np.ndarray:
+        """This shard's part of a per-row array in GLOBAL numbering (``ntotal_global`` entries, the same on every
+        rank), in local row order -- through the segment table."""
+        g = np.asarray(global_mask)
+        if g.shape[0] != self.ntotal_global:
+            raise ValueError(f"mask has {g.shape[0]} entries, the sharded index {self.ntotal_global} rows")
+        out = np.zeros(self.shard_sizes[self.rank], dtype=g.dtype)
+        for l0, g0, n in self.segments:
+            out[l0:l0 + n] = g[g0:g0 + n]
+        return out
+
+    def mark_deleted(self, global_ids) -> None:
+        """Tombstones: rows that no search may return any more (collective: every rank passes the same ids).  The rows
+        stay in HBM, as in the reference, until the caller compacts (``HybridStorage._rebuild_faiss_index``)."""
+        ids = np.asarray(list(global_ids), dtype=np.int64)
+        if ids.size == 0:
+            return
+        if self._dead is None or self._dead.shape[0] < self.ntotal_global:
+            grown = np.zeros(self.ntotal_global, dtype=bool)
+            if self._dead is not None:
+                grown[: self._dead.shape[0]] = self._dead
+            self._dead = grown
+        self._dead[ids] = True
+
+    def _local_allow(self, allow) -> Optional[np.ndarray]:
+        """Boolean mask over THIS shard's rows: the caller's global allow-mask minus the tombstones (None = every row)."""
+        dead = None
+        if self._dead is not None and self._dead.any():
+            dead = np.zeros(self.ntotal_global, dtype=bool)
+            dead[: self._dead.shape[0]] = self._dead
+        if allow is None and dead is None:
+            return None
+        g = np.ones(self.ntotal_global, dtype=bool) if allow is None else np.asarray(allow, dtype=bool)
+        if dead is not None:
+            g = g & ~dead
+        return self.local_rows_of(g)
+
+    def search_tensors(self, q, k: int, normalize: bool = False, allow=None):
+        """``q``: [nq, d] float32 tensor on this rank's device (same on all ranks).  ``allow``: optional boolean array
+        over the GLOBAL rows (same on all ranks): only rows marked True can be returned; every rank cuts its shard's
+        part out and hands it to the local masked search (``css_index_search_masked_dev``).
         Returns merged ``(D, I)`` tensors (global ids) on every rank."""
         import torch
 
@@ -166,11 +207,23 @@ class ShardedFlatIndex:
         send = torch.empty(record, dtype=torch.uint8, device=q.device)
         I = send[:ib].view(torch.int64).view(nq, k)
         D = send[ib:db].view(torch.float32).view(nq, k)
+        loc = self._local_allow(allow)
         if q.is_cuda:
             st = torch.cuda.current_stream().cuda_stream
-            self.local.search_dev(q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), st, normalize=normalize)
+            bits = None
+            if loc is not None and loc.shape[0]:
+                from .flat_index import pack_allow_bits
+
+                bits = torch.from_numpy(pack_allow_bits(loc, loc.shape[0]).view(np.int32)).to(q.device)
+            self.local.search_dev(q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), st, normalize=normalize,
+                                  allow_bits_ptr=bits.data_ptr() if bits is not None else 0)
+            if bits is not None:
+                bits.record_stream(torch.cuda.current_stream())
         else:  # CPU doubles (tests)
-            d_np, i_np = self.local.search(q.numpy(), k, normalize=normalize)
+            if loc is not None:
+                d_np, i_np = self.local.search(q.numpy(), k, normalize=normalize, allow=loc)
+            else:
+                d_np, i_np = self.local.search(q.numpy(), k, normalize=normalize)
             D.copy_(torch.from_numpy(d_np))
             I.copy_(torch.from_numpy(i_np))
         if len(self.segments) > 1:
@@ -196,11 +249,102 @@ class ShardedFlatIndex:
         Dg = recv[:, ib:db].view(torch.float32).view(self.world, nq, k)
         return self._merge(Dg.contiguous(), Ig.contiguous(), k)
 
-    def search(self, q: np.ndarray, k: int, normalize: bool = False):
+    def search(self, q: np.ndarray, k: int, normalize: bool = False, allow=None):
         import torch
 
         qt = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.d))
         if self.device_index is not None and torch.cuda.is_available():
             qt = qt.to(f"cuda:{self.device_index}")
-        D, I = self.search_tensors(qt, k, normalize)
+        D, I = self.search_tensors(qt, k, normalize, allow=allow)
         return D.cpu().numpy(), I.cpu().numpy()
+
+    # -- rows back out (index files, compaction) ---------------------------------------------------------------
+    def reconstruct_n(self, row0: int, n: int) -> np.ndarray:
+        """Rows ``[row0, row0 + n)`` in GLOBAL numbering on every rank (collective).  Each row lives on exactly one
+        shard: every rank fills in the rows it owns and ONE sum all-reduce of the zero-filled blocks completes them
+        (save / backup / compaction paths only -- never on the search path)."""
+        import torch
+
+        out = np.zeros((int(n), self.d), dtype=np.float32)
+        for l0, g0, m in self.segments:
+            lo, hi = max(g0, row0), min(g0 + m, row0 + n)
+            if hi > lo:
+                out[lo - row0:hi - row0] = self.local.reconstruct_n(l0 + (lo - g0), hi - lo)
+        if self.world > 1 and n:
+            t = torch.from_numpy(out)
+            if self.dist.get_backend(self.group) != "gloo":
+                t = t.to(f"cuda:{self.device_index or 0}")
+            self.dist.all_reduce(t, group=self.group)
+            out = t.cpu().numpy()
+        return out
+
+    def add_file_rows(self, path: str, offset: int, n: int, normalize: bool = False, chunk_rows: int = 1 << 18) -> None:
+        """``add_global`` of ``n`` fp32 rows stored row-major at byte ``offset`` of ``path`` (the payload of an index
+        file): every rank reads only its own block (collective call, no communication)."""
+        bounds = [shard_bounds(n, self.world, r) for r in range(self.world)]
+        lo, hi = bounds[self.rank]
+        if hi > lo:
+            if self.shard_sizes[self.rank] == 0:
+                self.local.reserve(hi - lo)
+            with open(path, "rb") as f:
+                for r0 in range(lo, hi, chunk_rows):
+                    m = min(chunk_rows, hi - r0)
+                    f.seek(offset + r0 * self.d * 4)
+                    buf = f.read(m * self.d * 4)
+                    if len(buf) != m * self.d * 4:
+                        raise RuntimeError("truncated index file (in rows)")
+                    self.local.add(np.frombuffer(buf, dtype=np.float32).reshape(m, self.d), normalize=normalize)
+        self._append_segment(hi - lo, self.ntotal_global + lo)
+        self._account([b[1] - b[0] for b in bounds], n)
+
+
+class ShardedIndexFacade:
+    """The members of ``flat_index.IndexFlat`` that ``HybridStorage`` touches, over a ``ShardedFlatIndex``: the
+    reference's ``Storage.search()`` behind 1..8 GPUs (``StorageConfig.sharded``).  SPMD: every rank of the process
+    group runs the same ``HybridStorage`` calls with the same arguments (adds, searches, deletes, saves); an ``add`` of
+    a file's chunks goes whole to the least-full shard (``add_routed``), a search is the local masked search + ONE
+    all-gather + merge, and ids are those of one ``IndexFlat`` that received the same calls."""
+
+    def __init__(self, d: int, metric: int = 0, device: int = 0, group=None, index_factory=None, merge=None):
+        self.sh = ShardedFlatIndex(d, metric, group=group, device_index=device, index_factory=index_factory, merge=merge)
+        self.d, self.metric_type, self.device, self.is_trained = int(d), int(metric), int(device), True
+
+    ntotal = property(lambda self: self.sh.ntotal_global)
+
+    def reserve(self, n: int) -> None:   # (shards grow on their own; a global reserve would over-allocate every shard)
+        pass
+
+    def add(self, x, normalize: bool = False) -> None:
+        a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.d)
+        if a.shape[0]:
+            self.sh.add_routed(a, normalize=normalize)
+
+    def search(self, q, k: int, normalize: bool = False, allow=None):
+        return self.sh.search(np.asarray(q, dtype=np.float32), int(k), normalize=normalize, allow=allow)
+
+    def reconstruct_n(self, row0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        return self.sh.reconstruct_n(int(row0), self.ntotal - int(row0) if n is None else int(n))
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        return self.reconstruct_n(int(i), 1)[0]
+
+    def mark_deleted(self, ids) -> None:
+        self.sh.mark_deleted(ids)
+
+    def set_search_mode(self, mode: str) -> None:
+        self.sh.local.set_search_mode(mode)
+
+    def close(self) -> None:
+        self.sh.local.close()
+
+
+def read_index_sharded(path: str, device: int = 0, group=None, index_factory=None, merge=None) -> ShardedIndexFacade:
+    """``flat_index.read_index`` for a shard group: the header is validated by the same code, then every rank reads
+    its own contiguous block of the rows (global ids = file order, as ``faiss.read_index`` numbers them)."""
+    from . import flat_index as fi
+
+    d, n, metric, offset = fi.read_index_header(path)
+    ix = ShardedIndexFacade(d, metric, device=device, group=group, index_factory=index_factory, merge=merge)
+    if n:
+        ix.sh.add_file_rows(path, offset, n)
+    return ix

@@ -65,6 +65,12 @@ class StorageConfig:
     # filtered search returns the true filtered top_k instead of whatever survives inside the first
     # ``max_results`` unfiltered hits.  Off by default: the reference's over-fetch semantics are kept bit for bit.
     filter_pushdown: bool = False
+    # extension (the reference pins faiss to one device, src/storage.py:283): row-shard the index over the
+    # ranks of the default torch.distributed process group, one process per GPU.  SPMD: every rank constructs the same
+    # HybridStorage (its own data_dir: SQLite and the index file are replicated per rank) and makes the same calls
+    # with the same arguments; search() is then the local masked search of every shard + ONE all-gather + merge.
+    # CSS_STORAGE_SHARDED=1 switches it on for an unmodified caller (the reference's CLI under torch.distributed.run).
+    sharded: bool = False
 
 
 @dataclass
@@ -180,6 +186,11 @@ class HybridStorage:
         """Name kept from the reference; the index is created in HBM."""
         kind = self.config.index_type
         if kind == "flat":
+            if self._sharded():
+                from .sharded import ShardedIndexFacade
+
+                metric = fi.METRIC_INNER_PRODUCT if self.config.normalize_embeddings else fi.METRIC_L2
+                return ShardedIndexFacade(self.embedding_dim, metric, device=self.config.device)
             cls = fi.IndexFlatIP if self.config.normalize_embeddings else fi.IndexFlatL2
             return cls(self.embedding_dim, device=self.config.device)
         if kind in ("ivf", "hnsw"):
@@ -187,6 +198,16 @@ class HybridStorage:
                 f"index type {kind!r} is not reachable from the product and is not implemented on MI355X; use 'flat'"
             )
         raise ValueError(f"Unknown index type: {kind}")
+
+    def _sharded(self) -> bool:
+        return bool(self.config.sharded) or os.environ.get("CSS_STORAGE_SHARDED") == "1"
+
+    def _read_index(self, path: str):
+        if self._sharded():
+            from .sharded import read_index_sharded
+
+            return read_index_sharded(path, device=self.config.device)
+        return fi.read_index(path, device=self.config.device)
 
     def _init_faiss(self) -> None:
         if self.config.use_gpu and self._gpu_capability is None:
@@ -231,7 +252,7 @@ class HybridStorage:
         if not self.index_path.exists():
             return
         try:
-            loaded = fi.read_index(str(self.index_path), device=self.config.device)
+            loaded = self._read_index(str(self.index_path))
             if loaded.d != self.embedding_dim:
                 raise RuntimeError(f"index file has d={loaded.d}, expected {self.embedding_dim}")
             self.faiss_index = loaded
@@ -314,7 +335,7 @@ class HybridStorage:
             ntotal = self.faiss_index.ntotal
             if ntotal == 0:
                 return []
-            k = min(cfg.max_results, ntotal)
+            k = min(cfg.max_results, ntotal, fi.MAX_K)   # (fi.MAX_K = 2048: beyond 128 the index takes passes of 128)
             if k <= 0:
                 return []
             # accepts ndarray or a plain list (tests/test_integration.py:203-204 of the reference)
@@ -637,7 +658,7 @@ class HybridStorage:
         with self._lock:
             ipath = src / self.config.index_name
             if ipath.exists():
-                self.faiss_index = fi.read_index(str(ipath), device=self.config.device)
+                self.faiss_index = self._read_index(str(ipath))
                 self._saved_rows = -1
             dpath = src / self.config.db_name
             if dpath.exists():

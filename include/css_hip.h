@@ -48,9 +48,12 @@ typedef enum css_status {
 
 enum { CSS_METRIC_IP = 0, CSS_METRIC_L2 = 1 };
 
-/* Largest k accepted by css_index_search (the reference asks for
- * min(max_results=100, ntotal): src/storage.py:432, :69). */
-#define CSS_MAX_K 128
+/* Largest k accepted by css_index_search.  The reference asks for
+ * k' = min(SearchConfig.max_results, ntotal) (src/storage.py:432; max_results
+ * defaults to 100, :69, and may be set to anything).  Up to 128 a search is one
+ * pass of the scan kernels; beyond, every query takes ceil(k / 128) passes over
+ * the rows the earlier passes did not return (still exact, still enqueue-only). */
+#define CSS_MAX_K 2048
 
 typedef struct css_devinfo {
     char name[128];

@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 N, D, K, G = 80_000_000, 768, 10, 8
 SHARD = N // G
-NQ, NQ_ORACLE = 1000, 8
+NQ, NQ_ORACLE = 1000, 32
 CHUNK = 2_000_000
 
 

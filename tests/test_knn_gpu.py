@@ -82,6 +82,93 @@ def test_k_values(k):
     _run_case(20000, 768, 2, k, 0, True, seed=k)
 
 
+@pytest.mark.parametrize("k", [129, 500, 2048])
+def test_k_beyond_one_kernel_pass(k):
+    """k > 128 (the reference passes k' = min(max_results, ntotal) for ANY max_results, src/storage.py:432): passes of
+    128 over the rows not returned yet + one sort; every search mode, single queries and a small batch, both metrics."""
+    _run_case(20000, 768, 1, k, 0, True, seed=k)
+    _run_case(6000, 768, 3, k, 1, False, seed=k + 1)
+    _run_case(3000, 100, 2, k, 0, True, seed=k + 2)
+    if k == 500:
+        _run_case(300, 768, 2, k, 0, True, seed=7)      # fewer rows than k: padded like faiss
+
+
+def test_k_beyond_one_pass_with_mask_duplicates_and_device_api():
+    import torch
+
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, d, k = 9000, 768, 300
+    base = synth.rows(n // 3, d, 31)
+    x = np.concatenate([base, base, base])                          # every row three times: ties inside and across passes
+    q = synth.rows(2, d, 32)
+    ix = IndexFlatIP(d)
+    ix.add(x, normalize=True)
+    allow = (np.arange(n) % 5) != 0
+    ref = ko.FlatIndexOracle(d, 0)
+    xr = ko.normalize_rows(x)
+    ref.add(xr[allow])
+    back = np.nonzero(allow)[0]
+    Dr, Ir = ref.search(ko.normalize_rows(q), k)
+    Ir = back[Ir]
+    D, I = ix.search(q, k, normalize=True, allow=allow)
+    # ties: a triplet that straddles a pass boundary (or rank k) is split lowest ids first, so the id SETS are the oracle's;
+    # inside the list two passes may have formed equal rows' scores in different summation orders (1 ulp): order by score
+    assert np.abs(D - Dr).max() < 1e-5 and (np.diff(D, axis=1) <= 0).all()
+    assert all(set(I[r].tolist()) == set(Ir[r].tolist()) for r in range(2))
+    # device-pointer twin, output rows strided by k
+    qd = torch.from_numpy(q).cuda()
+    Dd = torch.empty((2, k), dtype=torch.float32, device="cuda")
+    Id = torch.empty((2, k), dtype=torch.int64, device="cuda")
+    bits = torch.from_numpy(__import__("claude_semantic_search_amd.flat_index", fromlist=["x"]).pack_allow_bits(allow, n).view(np.int32)).cuda()
+    ix.search_dev(qd.data_ptr(), 2, k, Dd.data_ptr(), Id.data_ptr(), torch.cuda.current_stream().cuda_stream, normalize=True,
+                  allow_bits_ptr=bits.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(Id.cpu().numpy(), I) and np.array_equal(Dd.cpu().numpy(), D)
+    with pytest.raises(ValueError):
+        ix.search(q, 2049)
+    ix.close()
+
+
+def test_merge_of_shard_lists_with_k_beyond_128():
+    import ctypes
+
+    import torch
+
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlat
+    from claude_semantic_search_amd.sharded import packed_layout
+
+    n, d, G, nq, k = 4000, 128, 3, 3, 700
+    x = synth.rows(n, d, 41)
+    x[100:140] = x[60:100]                                          # ties across shards
+    q = synth.rows(nq, d, 42)
+    for metric in (0, 1):
+        whole = IndexFlat(d, metric)
+        whole.add(x, normalize=metric == 0)
+        D, I = whole.search(q, k, normalize=metric == 0)
+        ib, db, record = packed_layout(nq, k)
+        recv = torch.zeros((G, record), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        qd = torch.from_numpy(q).cuda()
+        bounds = [0, 90, 1500, n]                                    # shard 0 holds fewer rows than k: pads inside its list
+        keep = []
+        for g in range(G):
+            s_ = IndexFlat(d, metric)
+            s_.add(x[bounds[g]:bounds[g + 1]], normalize=metric == 0)
+            s_.set_id_base(bounds[g])
+            s_.search_dev(qd.data_ptr(), nq, k, recv[g, ib:db].view(torch.float32).data_ptr(), recv[g, :ib].view(torch.int64).data_ptr(),
+                          st, normalize=metric == 0)
+            keep.append(s_)
+        Do = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        Io = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        nat.check(nat.lib().css_merge_topk_packed_dev(ctypes.c_void_p(recv.data_ptr()), G, record, nq, k, metric,
+                                                      ctypes.c_void_p(Do.data_ptr()), ctypes.c_void_p(Io.data_ptr()), 0, ctypes.c_void_p(st)))
+        torch.cuda.synchronize()
+        assert np.array_equal(Io.cpu().numpy(), I) and np.abs(Do.cpu().numpy() - D).max() < 1e-5
+
+
 def test_k_larger_than_ntotal_pads():
     _run_case(7, 768, 2, 100, 0, True)
     _run_case(7, 768, 2, 100, 1, False)

@@ -36,9 +36,20 @@ class _FakeLocal:
     def add_synthetic(self, n, seed, first_row=0, normalize=True, stream=0):
         self.add(self.ko.synth_rows(n, self.d, seed, first_row), normalize)
 
-    def search(self, q, k, normalize=False):
-        D, I = self.o.search(self.ko.normalize_rows(q) if normalize else q, k)
-        return D, np.where(I >= 0, I + self.base, -1)
+    def search(self, q, k, normalize=False, allow=None):
+        qn = self.ko.normalize_rows(q) if normalize else q
+        if allow is None:
+            D, I = self.o.search(qn, k)
+            return D, np.where(I >= 0, I + self.base, -1)
+        sub = np.flatnonzero(np.asarray(allow, dtype=bool))      # masked search = the oracle over the allowed rows
+        o = self.ko.FlatIndexOracle(self.d, self.metric)
+        if sub.size:
+            o.add(self.o._xb[sub])
+        D, I = o.search(qn, k)
+        return D, np.where(I >= 0, sub[np.clip(I, 0, max(sub.size - 1, 0))] + self.base if sub.size else -1, -1)
+
+    def reconstruct_n(self, row0, n):
+        return self.o._xb[row0:row0 + n].copy()
 
 
 def _merge(metric):
@@ -96,6 +107,67 @@ def _worker_incremental(rank, world, port, out_dir):
         np.savez(os.path.join(out_dir, f"inc{rank}.npz"), D=D, I=I)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_masked(rank, world, port, out_dir):
+    """Allow-masks and tombstones through the shard group (global numbering, several segments per shard), k beyond one
+    kernel pass, and rows read back out of the shards."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from claude_semantic_search_amd import synth
+        from claude_semantic_search_amd.sharded import ShardedFlatIndex
+
+        d = 64
+        sh = ShardedFlatIndex(d, 0, index_factory=lambda: _FakeLocal(d, 0), merge=_merge(0))
+        sh.add_global(synth.rows(300, d, 51), normalize=True)
+        sh.add_routed(synth.rows(41, d, 52), normalize=True)
+        sh.add_global(synth.rows(200, d, 53), normalize=True)
+        n = sh.ntotal_global
+        allow = (np.arange(n) % 3) != 1
+        q = synth.rows(6, d, 54)
+        D1, I1 = sh.search(q, 10, normalize=True, allow=allow)
+        sh.mark_deleted([int(i) for i in I1[:, 0]] + [5, 340, n - 1])          # the best hit of every query + rows of every add
+        D2, I2 = sh.search(q, 10, normalize=True, allow=allow)                # mask AND tombstones
+        D3, I3 = sh.search(q, 300, normalize=True)                            # tombstones only, k beyond 128
+        rows = sh.reconstruct_n(290, 70)                                       # spans all three adds / both shards
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), D1=D1, I1=I1, D2=D2, I2=I2, D3=D3, I3=I3, rows=rows)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_masks_tombstones_large_k_and_row_export(tmp_path):
+    from oracle import knn_oracle as ko
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_masked, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = 64
+    x = ko.normalize_rows(np.concatenate([ko.synth_rows(300, d, 51), ko.synth_rows(41, d, 52), ko.synth_rows(200, d, 53)]))
+    n = x.shape[0]
+    qn = ko.normalize_rows(ko.synth_rows(6, d, 54))
+
+    def oracle(live, k):
+        sub = np.flatnonzero(live)
+        o = ko.FlatIndexOracle(d, 0)
+        o.add(x[sub])
+        D, I = o.search(qn, k)
+        return D, np.where(I >= 0, sub[np.clip(I, 0, sub.size - 1)], -1)
+
+    allow = (np.arange(n) % 3) != 1
+    Dr1, Ir1 = oracle(allow, 10)
+    dead = np.zeros(n, dtype=bool)
+    dead[[int(i) for i in Ir1[:, 0]] + [5, 340, n - 1]] = True
+    Dr2, Ir2 = oracle(allow & ~dead, 10)
+    Dr3, Ir3 = oracle(~dead, 300)
+    for r in range(2):
+        g = np.load(tmp_path / f"m{r}.npz")
+        for a, b in ((g["I1"], Ir1), (g["I2"], Ir2), (g["I3"], Ir3), (g["D1"], Dr1), (g["D2"], Dr2), (g["D3"], Dr3)):
+            assert np.array_equal(a, b), f"rank {r}"
+        assert np.array_equal(g["rows"], x[290:360])
 
 
 def test_two_rank_incremental_adds_number_rows_like_one_index(tmp_path):

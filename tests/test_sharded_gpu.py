@@ -103,6 +103,73 @@ def test_two_ranks_on_one_gpu_equal_the_cpu_oracle(tmp_path):
         assert_topk_matches(g["D1"], g["I1"], Dr[:1], Ir[:1], D64[:1], f"rank {r} single query")
 
 
+def _rank_masked(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from claude_semantic_search_amd import synth
+        from claude_semantic_search_amd.sharded import ShardedFlatIndex
+
+        torch.cuda.set_device(0)
+        sh = ShardedFlatIndex(768, 0, device_index=0)
+        sh.add_synthetic_global(200_000, seed=4, normalize=True)
+        sh.add_routed(synth.rows(700, 768, 8), normalize=True)
+        sh.add_global(synth.rows(1300, 768, 9), normalize=True)
+        n = sh.ntotal_global
+        allow = (np.arange(n) % 3) != 1
+        q = synth.rows(40, 768, 5)
+        D1, I1 = sh.search(q, 10, normalize=True, allow=allow)             # masked MFMA cascade on each shard
+        sh.mark_deleted([int(i) for i in I1[:, 0]] + [5, 200_100, n - 1])
+        D2, I2 = sh.search(q, 10, normalize=True, allow=allow)             # mask AND tombstones
+        D3, I3 = sh.search(q[:2], 300, normalize=True)                     # tombstones only, k beyond one kernel pass
+        rows = sh.reconstruct_n(199_990, 720)                              # spans the adds / both shards
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), D1=D1, I1=I1, D2=D2, I2=I2, D3=D3, I3=I3, rows=rows)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_masks_tombstones_and_large_k_equal_the_cpu_oracle(tmp_path):
+    import torch.multiprocessing as mp
+
+    from knn_checks import assert_topk_matches
+    from oracle import knn_oracle as ko
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_masked, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x = ko.normalize_rows(np.concatenate([ko.synth_rows(200_000, 768, 4), ko.synth_rows(700, 768, 8), ko.synth_rows(1300, 768, 9)]))
+    n = x.shape[0]
+    qn = ko.normalize_rows(ko.synth_rows(40, 768, 5))
+
+    def oracle(live, k, nq):
+        sub = np.flatnonzero(live)
+        o = ko.FlatIndexOracle(768, 0)
+        o.add(x[sub])
+        D, I = o.search(qn[:nq], k)
+        return D, sub[I], o.rescore64(qn[:nq], I)
+
+    allow = (np.arange(n) % 3) != 1
+    g0 = np.load(tmp_path / "m0.npz")
+    Dr1, Ir1, D641 = oracle(allow, 10, 40)
+    dead = np.zeros(n, dtype=bool)
+    dead[[int(i) for i in g0["I1"][:, 0]] + [5, 200_100, n - 1]] = True
+    Dr2, Ir2, D642 = oracle(allow & ~dead, 10, 40)
+    Dr3, Ir3, D643 = oracle(~dead, 300, 2)
+    for r in range(2):
+        g = np.load(tmp_path / f"m{r}.npz")
+        assert_topk_matches(g["D1"], g["I1"], Dr1, Ir1, D641, f"rank {r} masked")
+        assert_topk_matches(g["D2"], g["I2"], Dr2, Ir2, D642, f"rank {r} masked + tombstones")
+        assert_topk_matches(g["D3"], g["I3"], Dr3, Ir3, D643, f"rank {r} k = 300")
+        assert not dead[g["I2"]].any() and allow[g["I2"]].all() and not dead[g["I3"]].any()
+        assert np.allclose(g["rows"], x[199_990:200_710], rtol=0, atol=3e-7)
+
+
 def test_flagged_query_count_is_reported():
     from claude_semantic_search_amd import synth
     from claude_semantic_search_amd.flat_index import IndexFlatIP

@@ -40,6 +40,7 @@ struct LayerW {
     // LayerNorm-folded operands (k_fold_ln): the QKV weight carries gamma of the LayerNorm BEFORE this layer
     // (embedding LN / previous layer's output LN), the FFN1 weight gamma of this layer's attention LN
     bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
+    bf16_t* w2_p = nullptr;   // W2 in bf16 with the K order of the blocked FFN1 output (k_f32_to_bf16_kperm)
     float *dqkv = nullptr, *d1 = nullptr;   // d rows of the two folded GEMMs
     float *bo_f = nullptr, *b2_f = nullptr; // bias + beta of the LayerNorm whose output is the residual (EPI_RES)
 };
@@ -211,6 +212,7 @@ int build_params(css_encoder* e) {
         if (c.compute == 0) {
             CSS_HIP_TRY(hipMalloc((void**)&L.wqkv_f, (size_t)3 * H * H * 2));
             CSS_HIP_TRY(hipMalloc((void**)&L.w1_f, (size_t)F * H * 2));
+            CSS_HIP_TRY(hipMalloc((void**)&L.w2_p, (size_t)H * F * 2));
             CSS_HIP_TRY(hipMalloc((void**)&L.dqkv, (size_t)3 * H * 4));
             CSS_HIP_TRY(hipMalloc((void**)&L.d1, (size_t)F * 4));
             CSS_HIP_TRY(hipMalloc((void**)&L.bo_f, (size_t)H * 4));
@@ -238,11 +240,12 @@ int finalize_weights(css_encoder* e) {
             const float* g_in = li == 0 ? e->embg : e->layers[li - 1].ln2g;
             const float* b_in = li == 0 ? e->embb : e->layers[li - 1].ln2b;
             hipLaunchKernelGGL(k_fold_ln, dim3((3 * H + 3) / 4), dim3(256), 0, st, L.wqkv, g_in, b_in, L.bqkv, (int)(3 * H),
-                               (int)H, L.wqkv_f, L.dqkv);
+                               (int)H, L.wqkv_f, L.dqkv, 1);
             hipLaunchKernelGGL(k_fold_ln, dim3((F + 3) / 4), dim3(256), 0, st, L.w1, L.ln1g, L.ln1b, L.b1, (int)F, (int)H,
-                               L.w1_f, L.d1);
+                               L.w1_f, L.d1, 1);
             hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.bo, b_in, L.bo_f, (int)H);
             hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.b2, L.ln1b, L.b2_f, (int)H);
+            hipLaunchKernelGGL(k_f32_to_bf16_kperm, dim3(1024), dim3(256), 0, st, L.w2, L.w2_p, H * F, (int)F);
         }
     }
     for (auto& L : e->layers) {
@@ -332,12 +335,12 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
 }
 
 // k_gemm8p launch (256x256 tiles, persistent, one block per CU); `side` carries the LayerNorm-folding operands
-template <int EPI>
+template <int EPI, bool ABLK = false>
 int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   float qscale, const G8Side& side, int num_cus, hipStream_t st, const char* prof) {
     CSS_REQUIRE(N % 256 == 0 && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32), "gemm8p: bad shape %d x %d x %d", M, N, K);
     CSS_REQUIRE(EPI != EPI_RES || K >= 256, "gemm8p: EPI_RES needs K >= 256 (statistics are flushed in a tile's third K step)");
-    auto kern = k_gemm8p<EPI>;
+    auto kern = k_gemm8p<EPI, ABLK>;
     constexpr size_t lds = 2 * 4 * G8_HT;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
@@ -506,7 +509,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.stats_out = e->stats[1];
         side.cgroup = enc_env().cg_qkv;
         side.grid = enc_env().grid_qkv;
-        if ((rc = launch_gemm8p<EPI_AFF_QKV>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
+        if ((rc = launch_gemm8p<EPI_AFF_QKV, true>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
                                              side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
         {
@@ -529,14 +532,14 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.stats_out = e->stats[0];
         side.cgroup = enc_env().cg_ffn1;
         side.grid = enc_env().grid_ffn1;
-        if ((rc = launch_gemm8p<EPI_AFF_GELU>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
+        if ((rc = launch_gemm8p<EPI_AFF_GELU, true>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         // pre[0] = ffn W2^T + (b2 + beta1) + gamma1 (pre[1] - mu) rs; stats[0] += row sums
         side.pprev = pre[1];
         side.cvec = L.ln1g;
         side.cgroup = enc_env().cg_ffn2;
         side.grid = enc_env().grid_ffn2;
-        if ((rc = launch_gemm8p<EPI_RES>(e->ffn, L.w2_h, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
+        if ((rc = launch_gemm8p<EPI_RES, true>(e->ffn, L.w2_p, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         g_in = L.ln2g;
         b_in = L.ln2b;
@@ -632,7 +635,7 @@ int css_encoder_free(css_encoder* e) {
         if (L.wo_h) (void)hipFree(L.wo_h);
         if (L.w1_h) (void)hipFree(L.w1_h);
         if (L.w2_h) (void)hipFree(L.w2_h);
-        void* fp[] = {L.wqkv_f, L.w1_f, L.dqkv, L.d1, L.bo_f, L.b2_f};
+        void* fp[] = {L.wqkv_f, L.w1_f, L.w2_p, L.dqkv, L.d1, L.bo_f, L.b2_f};
         for (void* p : fp)
             if (p) (void)hipFree(p);
     }

@@ -98,8 +98,28 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
     }
 }
 
-// LayerNorm-folded path (k_gemm8p EPI_AFF_* / EPI_RES): the embedding sum is stored un-normalised as bf16 together
-// with the row sums of the STORED values in the fixed-point format of row_stats_decode (defined with k_gemm8p).
+// ---- the BLOCKED layout of the LayerNorm-folded path's `pre` tensors ([T][H] bf16, H % 64 == 0) ---------------------
+// A pre tensor is written by k_gemm8p<EPI_RES> and read back by the next EPI_RES GEMM (residual), by the EPI_AFF_* GEMMs
+// (A operand through LDS-DMA) and by the pooling.  It is stored in blocks of 16 tokens x 64 columns = 2 KiB, block
+// (t >> 4, c >> 6) at byte (t >> 4) * (H / 64) * 2048 + (c >> 6) * 2048, and inside a block in the ACCUMULATOR order of
+// the producing wave: 16-byte piece (j, lg, lq) at j * 1024 + lg * 256 + lq * 16 holds token row lq, columns
+// 16 (2 j) + 4 lg + {0..3} and 16 (2 j + 1) + 4 lg + {0..3} -- exactly the two v4f accumulators acc[m][2 j], acc[m][2 j + 1]
+// of lane lq + 16 lg.  So the producer stores, and the next EPI_RES GEMM re-reads, whole registers with 1-KiB-contiguous
+// wave instructions and NO LDS transpose (round 3's row-major pre went through the wave's LDS scratch twice per 16-row
+// block: O projection 2.00 ms, 28 % of the bf16 peak).  A consumer GEMM's LDS-DMA fetches 16-byte pieces by per-lane
+// addresses anyway; its K-step u = block column u, LDS chunk cl = piece (j = cl >> 2, lg = cl & 3), i.e. the K order
+// inside a 64-column block is permuted -- and the consumer's weights carry the same permutation (k_fold_ln, `perm`).
+__device__ __forceinline__ size_t preblk_elem(int t, int c, int H) {   // element index of (token t, column c)
+    return ((size_t)(t >> 4) * (H >> 6) + (c >> 6)) * 1024 + ((c >> 5) & 1) * 512 + ((c & 15) >> 2) * 128 + (t & 15) * 8 +
+           ((c >> 4) & 1) * 4 + (c & 3);
+}
+__host__ __device__ __forceinline__ int preblk_kpos(int k) {   // position of original column k in the permuted K order
+    const int cc = k & 63;
+    return (k & ~63) + ((((cc >> 5) & 1) * 4 + ((cc & 15) >> 2)) << 3) + ((cc >> 4) & 1) * 4 + (cc & 3);
+}
+
+// LayerNorm-folded path (k_gemm8p EPI_AFF_* / EPI_RES): the embedding sum is stored un-normalised as bf16 (blocked
+// layout above) together with the row sums of the STORED values in the fixed-point format of row_stats_decode.
 template <int H>
 __global__ __launch_bounds__(256) void k_embed_pre(const int32_t* __restrict__ ids, const int32_t* __restrict__ cu,
                                                    int B, const float* __restrict__ wemb,
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(256) void k_embed_pre(const int32_t* __restrict__ i
         const float4 a = w4[lane + 64 * i], b = p4[lane + 64 * i];
         ushort4 h;
         h.x = f2bf(a.x + b.x); h.y = f2bf(a.y + b.y); h.z = f2bf(a.z + b.z); h.w = f2bf(a.w + b.w);
-        reinterpret_cast<ushort4*>(pre + (size_t)t * H)[lane + 64 * i] = h;
+        *reinterpret_cast<ushort4*>(pre + preblk_elem(t, 4 * (lane + 64 * i), H)) = h;   // (4 columns = one 8-byte half piece)
         const float x = bf2f(h.x), y = bf2f(h.y), z = bf2f(h.z), w = bf2f(h.w);
         s1 += (x + y) + (z + w);
         s2 += (x * x + y * y) + (z * z + w * w);
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(256) void k_embed_pre(const int32_t* __restrict__ i
 //   Wf[j][k] = bf16(W[j][k] gamma[k] - mean_k(W[j][.] gamma[.])),   d[j] = sum_k beta[k] W[j][k] + bias[j].
 __global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, const float* __restrict__ bias,
-                                                 int N, int K, bf16_t* __restrict__ Wf, float* __restrict__ dvec) {
+                                                 int N, int K, bf16_t* __restrict__ Wf, float* __restrict__ dvec, int perm) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= N) return;
@@ -156,7 +176,8 @@ __global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, co
     }
     c = wave_allsum(c) / (float)K;
     d = wave_allsum(d);
-    for (int k = lane; k < K; k += 64) Wf[(size_t)j * K + k] = f2bf(fmaf(W[(size_t)j * K + k], gamma[k], -c));
+    // perm: the A operand is a pre tensor in the blocked layout, whose K order inside a 64-column block is permuted
+    for (int k = lane; k < K; k += 64) Wf[(size_t)j * K + (perm ? preblk_kpos(k) : k)] = f2bf(fmaf(W[(size_t)j * K + k], gamma[k], -c));
     if (lane == 0) dvec[j] = d + bias[j];
 }
 
@@ -821,7 +842,9 @@ constexpr int G8_HT = 16384;
 constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
 
 // `bias`: the bias row (EPI_QKV / EPI_GELU), bias + beta of the residual's LayerNorm (EPI_RES) or the d row (EPI_AFF_*)
-template <int EPI>
+// ABLK: the A operand is in the blocked layout (a pre tensor, or the FFN1 output read by FFN2); the output is written
+// in the blocked layout by EPI_RES (pre tensors) and EPI_AFF_GELU (the FFN1 output, whose only reader is FFN2's A side).
+template <int EPI, bool ABLK>
 __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                 const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
                                                 int K, int qscale_cols, float qscale, G8Side side) {
@@ -831,6 +854,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     constexpr bool RES = EPI == EPI_RES;
     constexpr bool DO_GELU = EPI == EPI_GELU || EPI == EPI_AFF_GELU;
     constexpr bool DO_QSCALE = EPI == EPI_QKV || EPI == EPI_AFF_QKV;
+    constexpr bool OBLK = RES || EPI == EPI_AFF_GELU;   // output in the blocked layout (preblk_elem): no LDS transpose in the epilogue
     constexpr int NW = 8, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][G8_HT]
     // side data of two tiles (parity): [0] bias / d row, [1] gamma row (RES), [2..5] 256 (sum, sum^2) pairs of 16 B
@@ -885,7 +909,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             srow_ = 16 * wave + prow;                                                                         \
             grow_ = c0_ + (srow_ >> 5) * 64 + ((KIND_) == G8_B1 ? 32 : 0) + (srow_ & 31);                     \
         }                                                                                                     \
-        srco[KIND_] = (unsigned)grow_ * (unsigned)K * 2u + ((pchunk ^ ((srow_ >> 1) & 7)) << 4);              \
+        if (ABLK && ((KIND_) == G8_A0 || (KIND_) == G8_A1)) {                                                 \
+            /* blocked pre tensor: this wave's 16 rows are ONE 16-row block; its 2 KiB at K step u are copied as they */ \
+            /* stand (two 1-KiB pieces, source and LDS destination both contiguous): lane = piece (lg, lq) of half j  */ \
+            srco[KIND_] = (unsigned)((r0_ + wr * 128 + ((KIND_) == G8_A1 ? 64 : 0) + wc * 16) >> 4) * (unsigned)(K >> 6) * 2048u + \
+                          (unsigned)lane * 16u;                                                               \
+        } else {                                                                                              \
+            srco[KIND_] = (unsigned)grow_ * (unsigned)K * 2u + ((pchunk ^ ((srow_ >> 1) & 7)) << 4);          \
+        }                                                                                                     \
     }
 // issue kind KIND_ of its next K step into buffer DB_, then advance that kind's cursor (past the block's last K
 // step the cursor keeps re-reading the last tile: harmless -- the slot it lands in is never read again -- and it
@@ -893,8 +924,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 #define G8_ISSUE(KIND_, DB_)                                                                                  \
     {                                                                                                         \
         const char* base_ = reinterpret_cast<const char*>(((KIND_) == G8_A0 || (KIND_) == G8_A1) ? A : W);    \
-        const unsigned o0_ = srco[KIND_] + (unsigned)it_kt[KIND_] * 128u;                                     \
-        const unsigned o1_ = (o0_ + row8) ^ 64u;                                                              \
+        const bool ablk_ = ABLK && ((KIND_) == G8_A0 || (KIND_) == G8_A1);   /* (blocked: K step = next 2-KiB block, half j = 1 follows) */ \
+        const unsigned o0_ = srco[KIND_] + (unsigned)it_kt[KIND_] * (ablk_ ? 2048u : 128u);                   \
+        const unsigned o1_ = ablk_ ? (o0_ + 1024u) : ((o0_ + row8) ^ 64u);                                    \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o0_),        \
             (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * G8_HT + dsto[KIND_]), 16, 0, 0); \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o1_),        \
@@ -963,7 +995,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 
     // fragment read offsets (bytes inside a slot): row r + 16 j keeps (r >> 1) & 7, so the rows of the j-th 16-row
     // tile are 2048 j bytes further; the second 32-wide k step is chunk ^ 4 = byte offset ^ 64
-    const int a_o0 = swz_byte(wr * 64 + lq, lg), a_o1 = a_o0 ^ 64;
+    // (ABLK: the A slot holds the blocked image itself -- block (wr, j) at (wr * 4 + j) * 2048, piece (c, lg, lq) of it at
+    // c * 1024 + lane * 16: a fragment read is 1 KiB of contiguous LDS, conflict free without a swizzle)
+    const int a_o0 = ABLK ? wr * 8192 + lane * 16 : swz_byte(wr * 64 + lq, lg), a_o1 = ABLK ? a_o0 + 1024 : (a_o0 ^ 64);
     const int b_o0 = swz_byte(wc * 32 + lq, lg), b_o1 = b_o0 ^ 64;
     v4f a[4][2], b0[2][2], b1[2][2];
 #define G8_READ_A(S_, D_)                                                                                     \
@@ -1129,29 +1163,31 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                     zp[lane + 64] = v4u{0u, 0u, 0u, 0u};
                 }
             }
-            // RES: gamma of this lane's 16 columns; the previous pre in whole 128-byte rows (lane: row lane >> 3 (+ 8) of a
-            // 16-row block, 16 bytes at column 8 (lane & 7): every cache line is requested once -- 8-byte pieces at the
-            // accumulator positions hit each line from 4 instructions and ran 10 us per tile slower), all requested before
-            // the first store of the epilogue (a wave's loads return in order behind its stores, whose acknowledgements
-            // take microseconds); each block goes through the wave's LDS scratch into the accumulator layout
+            // RES: gamma of this lane's 16 columns, (rs, mu rs) of its 8 rows, and the previous pre -- blocked layout
+            // (preblk_elem): the 16-byte piece (j, lg, lq) of block (16-row block m of this wave row, this wave's 64 columns)
+            // IS acc[m][2 j], acc[m][2 j + 1] of lane lq + 16 lg, so a wave instruction moves 1 KiB of contiguous bytes and
+            // nothing goes through LDS (round 3: two transposes per 16-row block through the wave's scratch).  All 16 loads
+            // are requested before the first store of the epilogue (a wave's loads return in order behind its stores).
             v4f gj[4];
             v4u pv[16];
-            const bf16_t* pb = nullptr;
             float keep[4] = {0.f, 0.f, 0.f, 0.f};   // row sums this lane reports: rows lq + 16 (lg + 4 j), (sum, sum^2)
+            // OBLK: byte offset of this lane's piece (m = 0, j = 0) in the blocked output (and previous pre); stride of m
+            const size_t blk_m = (size_t)(N >> 6) * 2048;
+            const size_t blk_o = ((size_t)(((tile / ntn) * BM + wr * 128) >> 4) * (N >> 6) + (size_t)((tile % ntn) * 4 + wc)) * 2048 + lane * 16;
             if constexpr (RES) {
                 const unsigned go_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][1][wc * 64 + 4 * lg];
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                              "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(gj[0]), "=&v"(gj[1]), "=&v"(gj[2]), "=&v"(gj[3])
                              : "v"(go_) : "memory");
-                pb = side.pprev + (size_t)((tile / ntn) * BM + wr * 128 + (lane >> 3)) * N + col0 + (lane & 7) * 8;
+                const char* pb = reinterpret_cast<const char*>(side.pprev) + blk_o;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
 #if defined(G8_EXP) && (G8_EXP & 2)
                     pv[2 * m] = pv[2 * m + 1] = v4u{0u, 0u, 0u, 0u};
 #else
-                    pv[2 * m] = *reinterpret_cast<const v4u*>(pb + (size_t)(16 * m) * N);
-                    pv[2 * m + 1] = *reinterpret_cast<const v4u*>(pb + (size_t)(16 * m + 8) * N);
+                    pv[2 * m] = *reinterpret_cast<const v4u*>(pb + m * blk_m);
+                    pv[2 * m + 1] = *reinterpret_cast<const v4u*>(pb + m * blk_m + 1024);
 #endif
                 }
             }
@@ -1159,19 +1195,20 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             for (int m = 0; m < 8; ++m) {
                 uint2 pk[4];
                 v4f s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
-                uint2 pq[4];
                 if constexpr (RES) {
-                    // rows of the previous pre -> accumulator layout; (rs, mu rs) of row lq + 16 m
-                    typedef float v2f __attribute__((ext_vector_type(2)));
-                    v2f st_;
-                    asm volatile("ds_write_b128 %5, %7\n\tds_write_b128 %5, %8 offset:%9\n\ts_waitcnt lgkmcnt(0)\n\t"
-                                 "ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_b64 %2, %6 offset:64\n\t"
-                                 "ds_read_b64 %3, %6 offset:96\n\tds_read_b64 %4, %10 offset:%11\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(pq[0]), "=&v"(pq[1]), "=&v"(pq[2]), "=&v"(pq[3]), "=&v"(st_)
-                                 : "v"(rbase), "v"(wbase), "v"(pv[2 * m]), "v"(pv[2 * m + 1]), "n"(8 * EPI_ROW), "v"(rso_), "n"(256 * m)
-                                 : "memory");
-                    rs_m[0] = st_[0];
-                    mrs_m[0] = st_[1];
+                    if ((m & 3) == 0) {   // (rs, mu rs) of four row blocks at a time (all eight up front: 8 registers too many)
+                        typedef float v2f __attribute__((ext_vector_type(2)));
+                        v2f st[4];
+                        asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\t"
+                                     "ds_read_b64 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(st[0]), "=&v"(st[1]), "=&v"(st[2]), "=&v"(st[3])
+                                     : "v"(rso_), "n"(256 * m), "n"(256 * m + 256), "n"(256 * m + 512), "n"(256 * m + 768) : "memory");
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            rs_m[i] = st[i][0];
+                            mrs_m[i] = st[i][1];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -1184,14 +1221,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                     }
                     if constexpr (RES) {
                         // acc holds branch + bias + beta; residual = gamma (p rs - mu rs) + beta
-                        const uint2 pw = pq[n];
+                        const unsigned pwx = pv[2 * m + (n >> 1)][2 * (n & 1)], pwy = pv[2 * m + (n >> 1)][2 * (n & 1) + 1];
                         v4f pf;
-                        pf[0] = __uint_as_float(pw.x << 16);
-                        pf[1] = __uint_as_float(pw.x & 0xFFFF0000u);
-                        pf[2] = __uint_as_float(pw.y << 16);
-                        pf[3] = __uint_as_float(pw.y & 0xFFFF0000u);
-                        const v4f u = __builtin_elementwise_fma(pf, v4f{rs_m[0], rs_m[0], rs_m[0], rs_m[0]},
-                                                                v4f{-mrs_m[0], -mrs_m[0], -mrs_m[0], -mrs_m[0]});
+                        pf[0] = __uint_as_float(pwx << 16);
+                        pf[1] = __uint_as_float(pwx & 0xFFFF0000u);
+                        pf[2] = __uint_as_float(pwy << 16);
+                        pf[3] = __uint_as_float(pwy & 0xFFFF0000u);
+                        const float rs_ = rs_m[m & 3], mrs_ = mrs_m[m & 3];
+                        const v4f u = __builtin_elementwise_fma(pf, v4f{rs_, rs_, rs_, rs_}, v4f{-mrs_, -mrs_, -mrs_, -mrs_});
                         v = __builtin_elementwise_fma(gj[n], u, v);
                         s1v += v;
                         s2v = __builtin_elementwise_fma(v, v, s2v);
@@ -1206,25 +1243,39 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                 }
                 if constexpr (RES) {
                     // row sums over this wave's 64 columns: 4 values per lane, then the 4 lanes lg = 0..3 of the row
+                    // (lane ^ 16, lane ^ 32: v_permlane16_swap / v_permlane32_swap on the VALU, no LDS crossbar)
                     float r1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), r2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
-                    r1 += __shfl_xor(r1, 16);
-                    r2 += __shfl_xor(r2, 16);
-                    r1 += __shfl_xor(r1, 32);
-                    r2 += __shfl_xor(r2, 32);
+                    {
+                        const auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+                        const auto a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2), __float_as_uint(r2), false, false);
+                        r1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                        r2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                        const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+                        const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r2), __float_as_uint(r2), false, false);
+                        r1 = __uint_as_float(b1[0]) + __uint_as_float(b1[1]);
+                        r2 = __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
+                    }
                     if (lg == (m & 3)) {
                         keep[2 * (m >> 2)] = r1;
                         keep[2 * (m >> 2) + 1] = r2;
                     }
                 }
-                v4u o0, o1;
-                asm volatile("ds_write_b64 %6, %2\n\tds_write_b64 %6, %3 offset:32\n\tds_write_b64 %6, %4 offset:64\n\t"
-                             "ds_write_b64 %6, %5 offset:96\n\ts_waitcnt lgkmcnt(0)\n\t"
-                             "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(o0), "=&v"(o1)
-                             : "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(wbase), "v"(rbase), "n"(8 * EPI_ROW)
-                             : "memory");
-                __builtin_nontemporal_store(o0, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m) * N));
-                __builtin_nontemporal_store(o1, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m + 8) * N));
+                if constexpr (OBLK) {
+                    // blocked layout: this lane's two 16-byte pieces of block m, straight from the registers
+                    char* cb_ = reinterpret_cast<char*>(Cout) + blk_o + m * blk_m;
+                    __builtin_nontemporal_store(v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, reinterpret_cast<v4u*>(cb_));
+                    __builtin_nontemporal_store(v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y}, reinterpret_cast<v4u*>(cb_ + 1024));
+                } else {
+                    v4u o0, o1;
+                    asm volatile("ds_write_b64 %6, %2\n\tds_write_b64 %6, %3 offset:32\n\tds_write_b64 %6, %4 offset:64\n\t"
+                                 "ds_write_b64 %6, %5 offset:96\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(o0), "=&v"(o1)
+                                 : "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(wbase), "v"(rbase), "n"(8 * EPI_ROW)
+                                 : "memory");
+                    __builtin_nontemporal_store(o0, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m) * N));
+                    __builtin_nontemporal_store(o1, reinterpret_cast<v4u*>(cbase + (size_t)(16 * m + 8) * N));
+                }
             }
             if constexpr (RES) {
                 // Row sums over this wave's 64 columns: lane (lq, lg) holds rows 16 lg + lq and 64 + 16 lg + lq of the wave
@@ -1714,7 +1765,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_ln(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int c = tid + 256 * i;
-            if (c < H) acc[i] += fmaf(bf2f(pre[(size_t)(t0 + t) * H + c]), rs, -mrs);
+            if (c < H) acc[i] += fmaf(bf2f(pre[preblk_elem(t0 + t, c, H)]), rs, -mrs);   // (blocked layout, see k_embed_pre)
         }
     }
 #pragma unroll
@@ -1755,6 +1806,18 @@ __global__ __launch_bounds__(256) void k_pool_final(const float* __restrict__ pa
 }
 
 // ---------------------------------------------------------------- weights
+// [N][K] fp32 -> bf16 with the K order of the blocked activation layout (preblk_kpos): the weights of a GEMM whose A
+// operand is a blocked tensor (FFN2 reading the blocked FFN1 output).
+__global__ void k_f32_to_bf16_kperm(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n, int K) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const size_t row = i / (size_t)K;
+        const int k = (int)(i - row * (size_t)K);
+        out[row * (size_t)K + preblk_kpos(k)] = f2bf(in[i]);
+    }
+}
+
 __global__ void k_f32_to_bf16(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;

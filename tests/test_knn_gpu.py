@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
-def _run_case(n, d, nq, k, metric, normalize, seed=1):
+def _run_case(n, d, nq, k, metric, normalize, seed=1, tie_eps=1e-6):
     from oracle import knn_oracle as ko
     from claude_semantic_search_amd.flat_index import IndexFlat
 
@@ -32,7 +32,7 @@ def _run_case(n, d, nq, k, metric, normalize, seed=1):
     for mode in ("exact_fp32", "coarse", "auto"):
         hip.set_search_mode(mode)
         D, I = hip.search(q, k, normalize=normalize)
-        assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}")
+        assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}", tie_eps=tie_eps)
     hip.close()
 
 
@@ -87,7 +87,8 @@ def test_k_beyond_one_kernel_pass(k):
     """k > 128 (the reference passes k' = min(max_results, ntotal) for ANY max_results, src/storage.py:432): passes of
     128 over the rows not returned yet + one sort; every search mode, single queries and a small batch, both metrics."""
     _run_case(20000, 768, 1, k, 0, True, seed=k)
-    _run_case(6000, 768, 3, k, 1, False, seed=k + 1)
+    # (squared L2 of raw N(0,1) rows: distances ~1500, one fp32 ulp there is 1.2e-4 -- ranks closer than that may swap)
+    _run_case(6000, 768, 3, k, 1, False, seed=k + 1, tie_eps=1e-3)
     _run_case(3000, 100, 2, k, 0, True, seed=k + 2)
     if k == 500:
         _run_case(300, 768, 2, k, 0, True, seed=7)      # fewer rows than k: padded like faiss
@@ -690,7 +691,7 @@ def test_invalid_arguments_raise():
     with pytest.raises(ValueError):
         ix.search(np.zeros((1, 8), np.float32), 0)
     with pytest.raises(ValueError):
-        ix.search(np.zeros((1, 8), np.float32), 129)
+        ix.search(np.zeros((1, 8), np.float32), 2049)
     D, I = ix.search(np.zeros((1, 8), np.float32), 3)  # empty index: padded
     assert I[0].tolist() == [-1, -1, -1]
 

@@ -282,10 +282,11 @@ int ensure_acts(css_encoder* e, int T, int B) {
         const size_t cap = ((size_t)T + 255) / 256 * 256 + 256;
         CSS_HIP_TRY(hipMalloc((void**)&e->x32, cap * H * 4));
         CSS_HIP_TRY(hipMalloc((void**)&e->pre32, cap * H * 4));
-        CSS_HIP_TRY(hipMalloc((void**)&e->x16, cap * H * es));
+        // (+ cap * 64 bytes: the padding of the blocked layout the LayerNorm-folded path keeps in x16 / pre32 / ffn)
+        CSS_HIP_TRY(hipMalloc((void**)&e->x16, cap * H * es + cap * 64));
         CSS_HIP_TRY(hipMalloc((void**)&e->qkv, cap * 3 * H * es));
         CSS_HIP_TRY(hipMalloc((void**)&e->ctx, cap * H * es));
-        CSS_HIP_TRY(hipMalloc((void**)&e->ffn, cap * F * es));
+        CSS_HIP_TRY(hipMalloc((void**)&e->ffn, cap * F * es + cap * 64));
         CSS_HIP_TRY(hipMalloc((void**)&e->ids_dev, cap * sizeof(int32_t)));
         e->stats[0] = e->stats[1] = nullptr;
         if (c.compute == 0) {

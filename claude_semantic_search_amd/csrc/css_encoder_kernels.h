@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
 // ---- the BLOCKED layout of the LayerNorm-folded path's `pre` tensors ([T][H] bf16, H % 64 == 0) ---------------------
 // A pre tensor is written by k_gemm8p<EPI_RES> and read back by the next EPI_RES GEMM (residual), by the EPI_AFF_* GEMMs
 // (A operand through LDS-DMA) and by the pooling.  It is stored in blocks of 16 tokens x 64 columns = 2 KiB, block
-// (t >> 4, c >> 6) at byte (t >> 4) * (H / 64) * 2048 + (c >> 6) * 2048, and inside a block in the ACCUMULATOR order of
+// (t >> 4, c >> 6) at byte (t >> 4) * preblk_rowstride(H) + (c >> 6) * 2048, and inside a block in the ACCUMULATOR order of
 // the producing wave: 16-byte piece (j, lg, lq) at j * 1024 + lg * 256 + lq * 16 holds token row lq, columns
 // 16 (2 j) + 4 lg + {0..3} and 16 (2 j + 1) + 4 lg + {0..3} -- exactly the two v4f accumulators acc[m][2 j], acc[m][2 j + 1]
 // of lane lq + 16 lg.  So the producer stores, and the next EPI_RES GEMM re-reads, whole registers with 1-KiB-contiguous
@@ -109,9 +109,16 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
 // block: O projection 2.00 ms, 28 % of the bf16 peak).  A consumer GEMM's LDS-DMA fetches 16-byte pieces by per-lane
 // addresses anyway; its K-step u = block column u, LDS chunk cl = piece (j = cl >> 2, lg = cl & 3), i.e. the K order
 // inside a 64-column block is permuted -- and the consumer's weights carry the same permutation (k_fold_ln, `perm`).
+// Bytes from one 16-row block row to the next: the H / 64 blocks + CSS_PREBLK_PAD bytes of padding.  Without it the
+// stride is a multiple of 4 KiB (768 columns: 24 KiB, 3072: 96 KiB), and the eight waves of a GEMM block, which fetch
+// eight consecutive block rows at the same K step, all land on the same L2 channels (256-byte interleave).
+#ifndef CSS_PREBLK_PAD
+#define CSS_PREBLK_PAD 0
+#endif
+__host__ __device__ __forceinline__ size_t preblk_rowstride(int H) { return (size_t)(H >> 6) * 2048 + CSS_PREBLK_PAD; }
 __device__ __forceinline__ size_t preblk_elem(int t, int c, int H) {   // element index of (token t, column c)
-    return ((size_t)(t >> 4) * (H >> 6) + (c >> 6)) * 1024 + ((c >> 5) & 1) * 512 + ((c & 15) >> 2) * 128 + (t & 15) * 8 +
-           ((c >> 4) & 1) * 4 + (c & 3);
+    return ((size_t)(t >> 4) * preblk_rowstride(H) + (size_t)(c >> 6) * 2048) / 2 + ((c >> 5) & 1) * 512 + ((c & 15) >> 2) * 128 +
+           (t & 15) * 8 + ((c >> 4) & 1) * 4 + (c & 3);
 }
 __host__ __device__ __forceinline__ int preblk_kpos(int k) {   // position of original column k in the permuted K order
     const int cc = k & 63;
@@ -912,7 +919,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         if (ABLK && ((KIND_) == G8_A0 || (KIND_) == G8_A1)) {                                                 \
             /* blocked pre tensor: this wave's 16 rows are ONE 16-row block; its 2 KiB at K step u are copied as they */ \
             /* stand (two 1-KiB pieces, source and LDS destination both contiguous): lane = piece (lg, lq) of half j  */ \
-            srco[KIND_] = (unsigned)((r0_ + wr * 128 + ((KIND_) == G8_A1 ? 64 : 0) + wc * 16) >> 4) * (unsigned)(K >> 6) * 2048u + \
+            srco[KIND_] = (unsigned)((r0_ + wr * 128 + ((KIND_) == G8_A1 ? 64 : 0) + wc * 16) >> 4) * (unsigned)preblk_rowstride(K) + \
                           (unsigned)lane * 16u;                                                               \
         } else {                                                                                              \
             srco[KIND_] = (unsigned)grow_ * (unsigned)K * 2u + ((pchunk ^ ((srow_ >> 1) & 7)) << 4);          \
@@ -1172,8 +1179,8 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             v4u pv[16];
             float keep[4] = {0.f, 0.f, 0.f, 0.f};   // row sums this lane reports: rows lq + 16 (lg + 4 j), (sum, sum^2)
             // OBLK: byte offset of this lane's piece (m = 0, j = 0) in the blocked output (and previous pre); stride of m
-            const size_t blk_m = (size_t)(N >> 6) * 2048;
-            const size_t blk_o = ((size_t)(((tile / ntn) * BM + wr * 128) >> 4) * (N >> 6) + (size_t)((tile % ntn) * 4 + wc)) * 2048 + lane * 16;
+            const size_t blk_m = preblk_rowstride(N);
+            const size_t blk_o = (size_t)(((tile / ntn) * BM + wr * 128) >> 4) * blk_m + (size_t)((tile % ntn) * 4 + wc) * 2048 + lane * 16;
             if constexpr (RES) {
                 const unsigned go_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sbias[par][1][wc * 64 + 4 * lg];
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
@@ -1263,8 +1270,16 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                 if constexpr (OBLK) {
                     // blocked layout: this lane's two 16-byte pieces of block m, straight from the registers
                     char* cb_ = reinterpret_cast<char*>(Cout) + blk_o + m * blk_m;
-                    __builtin_nontemporal_store(v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, reinterpret_cast<v4u*>(cb_));
-                    __builtin_nontemporal_store(v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y}, reinterpret_cast<v4u*>(cb_ + 1024));
+                    if constexpr (RES) {
+                        // a pre tensor (151 MB at 256 x 384) is the A operand of the very next GEMM: plain stores leave it in the
+                        // Infinity Cache for that reader (measured in one session: 18.64 -> 18.48 ms per forward; plain stores of
+                        // the 450 / 600 MB qkv and FFN1 outputs, which cannot stay resident, cost 0.05 / 0.2 ms instead)
+                        *reinterpret_cast<v4u*>(cb_) = v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+                        *reinterpret_cast<v4u*>(cb_ + 1024) = v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y};
+                    } else {
+                        __builtin_nontemporal_store(v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, reinterpret_cast<v4u*>(cb_));
+                        __builtin_nontemporal_store(v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y}, reinterpret_cast<v4u*>(cb_ + 1024));
+                    }
                 } else {
                     v4u o0, o1;
                     asm volatile("ds_write_b64 %6, %2\n\tds_write_b64 %6, %3 offset:32\n\tds_write_b64 %6, %4 offset:64\n\t"

@@ -40,7 +40,7 @@ struct LayerW {
     // LayerNorm-folded operands (k_fold_ln): the QKV weight carries gamma of the LayerNorm BEFORE this layer
     // (embedding LN / previous layer's output LN), the FFN1 weight gamma of this layer's attention LN
     bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
-    bf16_t* w2_p = nullptr;   // W2 in bf16 with the K order of the blocked FFN1 output (k_f32_to_bf16_kperm)
+    bf16_t *w2_p = nullptr, *wo_p = nullptr;   // W2 / Wo in bf16 with the K order of their blocked A operands (k_f32_to_bf16_kperm)
     float *dqkv = nullptr, *d1 = nullptr;   // d rows of the two folded GEMMs
     float *bo_f = nullptr, *b2_f = nullptr; // bias + beta of the LayerNorm whose output is the residual (EPI_RES)
 };
@@ -213,6 +213,7 @@ int build_params(css_encoder* e) {
             CSS_HIP_TRY(hipMalloc((void**)&L.wqkv_f, (size_t)3 * H * H * 2));
             CSS_HIP_TRY(hipMalloc((void**)&L.w1_f, (size_t)F * H * 2));
             CSS_HIP_TRY(hipMalloc((void**)&L.w2_p, (size_t)H * F * 2));
+            CSS_HIP_TRY(hipMalloc((void**)&L.wo_p, (size_t)H * H * 2));
             CSS_HIP_TRY(hipMalloc((void**)&L.dqkv, (size_t)3 * H * 4));
             CSS_HIP_TRY(hipMalloc((void**)&L.d1, (size_t)F * 4));
             CSS_HIP_TRY(hipMalloc((void**)&L.bo_f, (size_t)H * 4));
@@ -246,6 +247,7 @@ int finalize_weights(css_encoder* e) {
             hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.bo, b_in, L.bo_f, (int)H);
             hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, st, L.b2, L.ln1b, L.b2_f, (int)H);
             hipLaunchKernelGGL(k_f32_to_bf16_kperm, dim3(1024), dim3(256), 0, st, L.w2, L.w2_p, H * F, (int)F);
+            hipLaunchKernelGGL(k_f32_to_bf16_kperm, dim3(1024), dim3(256), 0, st, L.wo, L.wo_p, H * H, (int)H);
         }
     }
     for (auto& L : e->layers) {
@@ -454,7 +456,7 @@ int forward_typed(css_encoder* e, const int32_t* ids, const int32_t* cu, int B, 
             if constexpr (BF) {
                 const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
                 const int nqb = (max_len + 127) / 128;
-                hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st,
+                hipLaunchKernelGGL((k_attention_bf16<64, false>), dim3(B * nqb * c.heads), dim3(256), lds, st,
                                    (const bf16_t*)e->qkv, cu, e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads, e->att_range);
             } else {
                 hipLaunchKernelGGL(k_attention_f32, dim3(B, max_len, c.heads), dim3(64), 0, st, (const float*)e->qkv, cu,
@@ -517,7 +519,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
             ProfScope ps("enc_attention", st);
             const size_t lds = 4 * 8192 + (size_t)(2 * maxL - 1 + 64) * 4;
             const int nqb = (max_len + 127) / 128;
-            hipLaunchKernelGGL(k_attention_bf16<64>, dim3(B * nqb * c.heads), dim3(256), lds, st, (const bf16_t*)e->qkv, cu,
+            hipLaunchKernelGGL((k_attention_bf16<64, true>), dim3(B * nqb * c.heads), dim3(256), lds, st, (const bf16_t*)e->qkv, cu,
                                e->bias_tab, maxL, H, (bf16_t*)e->ctx, nqb, c.heads, e->att_range);
             CSS_LAUNCH_CHECK();
         }
@@ -526,7 +528,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.cvec = g_in;
         side.cgroup = enc_env().cg_o;
         side.grid = enc_env().grid_o;
-        if ((rc = launch_gemm8p<EPI_RES>(e->ctx, L.wo_h, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
+        if ((rc = launch_gemm8p<EPI_RES, true>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
         side.stats_in = e->stats[1];
@@ -636,7 +638,7 @@ int css_encoder_free(css_encoder* e) {
         if (L.wo_h) (void)hipFree(L.wo_h);
         if (L.w1_h) (void)hipFree(L.w1_h);
         if (L.w2_h) (void)hipFree(L.w2_h);
-        void* fp[] = {L.wqkv_f, L.w1_f, L.w2_p, L.dqkv, L.d1, L.bo_f, L.b2_f};
+        void* fp[] = {L.wqkv_f, L.w1_f, L.w2_p, L.wo_p, L.dqkv, L.d1, L.bo_f, L.b2_f};
         for (void* p : fp)
             if (p) (void)hipFree(p);
     }

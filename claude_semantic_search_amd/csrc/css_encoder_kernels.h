@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     constexpr bool RES = EPI == EPI_RES;
     constexpr bool DO_GELU = EPI == EPI_GELU || EPI == EPI_AFF_GELU;
     constexpr bool DO_QSCALE = EPI == EPI_QKV || EPI == EPI_AFF_QKV;
-    constexpr bool OBLK = RES || EPI == EPI_AFF_GELU;   // output in the blocked layout (preblk_elem): no LDS transpose in the epilogue
+    constexpr bool OBLK = RES || AFF;   // output in the blocked layout (preblk_elem): no LDS transpose in the epilogue
     constexpr int NW = 8, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][4][G8_HT]
     // side data of two tiles (parity): [0] bias / d row, [1] gamma row (RES), [2..5] 256 (sum, sum^2) pairs of 16 B
@@ -1446,27 +1446,50 @@ __device__ __forceinline__ int vswz_byte(int row, int chunk) { return row * 128 
 // true, the online softmax with a running maximum (reference 0 until a score exceeds it).  Attention logits of
 // a trained encoder are a few tens at most (|score| < 69 = 100 ln 2 is the fast path's range), so the repeat is a
 // guard, not a path that runs; tests force it with CSS_ATT_RANGE=0.
-template <int HD, bool SAFE>
+// BLK: qkv is in the blocked layout of k_gemm8p's EPI_AFF_QKV epilogue (preblk_elem with H = 3 * hidden: head h of
+// q / k / v = block column h / heads + h / 2 heads + h; 16-byte piece cl = 4 j + lg of a token = dims 32 j + 4 lg + {0..3}
+// and 32 j + 16 + 4 lg + {0..3}).  K tile rows in LDS keep the pieces in piece order (the q fragments are the same pieces
+// of the q block, so QK^T contracts matching dims); the V tile is kept as the block image itself with the 16-byte slots
+// of piece row lg rotated by 4 lg (vblk_byte) and the transposed reads address ACTUAL dims, so the output is in
+// natural dim order.  A staging wave instruction covers 4 pieces x 16 consecutive keys = 4 x 256 contiguous bytes.
+__device__ __forceinline__ int vblk_byte(int key, int cl) {   // V tile (64 keys) in BLK mode: slot of piece cl of key
+    return (key >> 4) * 2048 + (cl >> 2) * 1024 + (cl & 3) * 256 + (((key & 15) ^ ((cl & 3) << 2)) << 4);
+}
+template <int HD, bool SAFE, bool BLK>
 __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char* Ks, char* Vs, const float* bt, int tok0, int L,
                                            int head, int hidden, int maxL, int qic, const v4f (&qf)[4], f32x16 (&oacc)[2]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int fr = lane & 31, fh = lane >> 5;
     const int ld = 3 * hidden;  // row stride of qkv in elements
     const int nkt = (L + 63) / 64;
-    const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
+    // staging, 2 passes of 32 keys x 8 chunks.  Row-major qkv: 8 lanes = the 8 chunks of one key row.  BLK: 16 lanes = one
+    // piece of 16 consecutive keys (even keys first: the K tile's swizzle then spreads 8 lanes over 8 bank groups)
+    const int srow = BLK ? 2 * (tid & 7) + ((tid >> 3) & 1) + 16 * (tid >> 7) : tid >> 3;
+    const int schunk = BLK ? (tid >> 4) & 7 : tid & 7;
+    const unsigned brs = (unsigned)(preblk_rowstride(ld) / 2);   // BLK: elements per 16-token block row (T * 3 hidden < 2^31)
+    const unsigned poff = (unsigned)((schunk >> 2) * 512 + (schunk & 3) * 128);
+    const bf16_t* kblk = qkv + (size_t)(head + hidden / 64) * 1024;
+    const bf16_t* vblk = qkv + (size_t)(head + hidden / 32) * 1024;
     v4f rk[2], rv[2];
 #define AT_GLOAD(KT_)                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
         int key = (KT_) * 64 + srow + 32 * i;                                                       \
         key = key < L ? key : L - 1;                                                                \
-        const bf16_t* base = qkv + (size_t)(tok0 + key) * ld + head * HD + schunk * 8;              \
-        rk[i] = *reinterpret_cast<const v4f*>(base + hidden);                                       \
-        rv[i] = *reinterpret_cast<const v4f*>(base + 2 * hidden);                                   \
+        if constexpr (BLK) {   /* uniform base (k / v block column of this head) + a 32-bit element offset per lane */ \
+            const unsigned t_ = (unsigned)(tok0 + key);                                             \
+            const unsigned o_ = (t_ >> 4) * brs + (t_ & 15u) * 8u + poff;                           \
+            rk[i] = *reinterpret_cast<const v4f*>(kblk + o_);                                       \
+            rv[i] = *reinterpret_cast<const v4f*>(vblk + o_);                                       \
+        } else {                                                                                    \
+            const bf16_t* base = qkv + (size_t)(tok0 + key) * ld + head * HD + schunk * 8;          \
+            rk[i] = *reinterpret_cast<const v4f*>(base + hidden);                                   \
+            rv[i] = *reinterpret_cast<const v4f*>(base + 2 * hidden);                               \
+        }                                                                                           \
     }
 #define AT_SSTORE(BUF)                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
         *reinterpret_cast<v4f*>(Ks + (BUF) * 8192 + swz_byte(srow + 32 * i, schunk)) = rk[i];       \
-        *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + vswz_byte(srow + 32 * i, schunk)) = rv[i];      \
+        *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + (BLK ? vblk_byte(srow + 32 * i, schunk) : vswz_byte(srow + 32 * i, schunk))) = rv[i]; \
     }
     AT_GLOAD(0)
     AT_SSTORE(0)
@@ -1481,6 +1504,9 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
     const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int vflip = (q4 >> 1) & 1;   // = bit 1 of the key row (the other row terms are multiples of 4)
     const int vlane = (4 * fh + q4) * 128 + 32 * g16 + 8 * p4;   // + (16 st [+ 8]) * 128 + ((mt ^ vflip) * 64)
+    // BLK: key row 16 (2 sub + st) + 4 fh + q4 (+ 8), dims 32 mt + 16 g16 + 4 p4 + {0..3} = half g16 of piece (j = mt, lg = p4):
+    // block (2 sub + st) * 2048 + mt * 1024 + p4 * 256 + ((4 fh + q4 (+ 8)) ^ 4 p4) * 16 + 8 g16
+    const int vlane_b = p4 * 256 + (((4 * fh + q4) ^ (4 * p4)) << 4) + 8 * g16;   // (+ 8 keys: slot ^ 8 = byte offset ^ 128)
 
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -1491,6 +1517,7 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
 #endif
         const char* Kb = Ks + cur * 8192;
         const char* Vb = Vs + cur * 8192;
+
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int key0 = kt * 64 + sub * 32;
@@ -1576,9 +1603,15 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     // lane (d = 32*mt + fr, half fh): keys {16st+4fh+0..3} and {16st+8+4fh+0..3}
-                    const char* vp = Vb + vlane + (sub * 32 + 16 * st) * 128 + ((mt ^ vflip) << 6);
+                    // (BLK: the lane offset is made opaque per read pair: with plain loop-invariant addresses hipcc hoists
+                    // the transposed reads of a whole tile, 248 bytes of scratch per lane and Q fragments reloaded in the loop)
+                    int vo_ = vlane_b;
+                    if constexpr (BLK) asm volatile("" : "+v"(vo_));
+                    const char* vp = BLK ? Vb + vo_ + ((2 * sub + st) * 2048 + mt * 1024)
+                                         : Vb + vlane + (sub * 32 + 16 * st) * 128 + ((mt ^ vflip) << 6);
+                    const char* vp_hi = BLK ? Vb + (vo_ ^ 128) + ((2 * sub + st) * 2048 + mt * 1024) : vp + 8 * 128;
                     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(vp));
-                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(vp + 8 * 128));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(vp_hi));
                     // whole-vector shuffle + bitcast: per-element short -> __bf16 bitcasts of the
                     // tr-read result were miscompiled by hipcc 7.2 into a splat of element 0
                     const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1604,7 +1637,7 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
 }
 
 // `range`: the fast pass is kept when every row sum lies in (1 / range, range); 0 forces the SAFE pass (tests).
-template <int HD>
+template <int HD, bool BLK>
 __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         const float* __restrict__ bias_tab, int maxL, int hidden,
                                                         bf16_t* __restrict__ ctx, int nqb, int heads, float range) {
@@ -1635,9 +1668,16 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     // Q fragments as B operand: lane holds Q[query][16*ks + 8*fh + j]
     v4f qf[4];
     {
-        const bf16_t* qp = qkv + (size_t)(tok0 + qic) * (3 * hidden) + head * HD;
+        if constexpr (BLK) {   // piece cl = 2 ks + fh of this token's row in the q block of `head` (see attn_pass)
+            const int t_ = tok0 + qic;
+            const bf16_t* qp = qkv + (size_t)(t_ >> 4) * (preblk_rowstride(3 * hidden) / 2) + (size_t)head * 1024 + (t_ & 15) * 8;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v4f*>(qp + 16 * ks + 8 * fh);
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v4f*>(qp + (ks >> 1) * 512 + (2 * (ks & 1) + fh) * 128);
+        } else {
+            const bf16_t* qp = qkv + (size_t)(tok0 + qic) * (3 * hidden) + head * HD;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v4f*>(qp + 16 * ks + 8 * fh);
+        }
     }
     {
         const float* bsrc = bias_tab + (size_t)head * (2 * maxL - 1);
@@ -1655,11 +1695,35 @@ __global__ __launch_bounds__(256, 4) void k_attention_bf16(const bf16_t* __restr
     float ltot = 0.f;
     bool ok = false;
     if (range > 0.f) {
-        ltot = attn_pass<HD, false>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
+        ltot = attn_pass<HD, false, BLK>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
         ok = ltot < range && ltot * range > 1.0f;   // (NaN compares false)
     }
-    if (!__syncthreads_and(ok)) ltot = attn_pass<HD, true>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
+    if (!__syncthreads_and(ok)) ltot = attn_pass<HD, true, BLK>(qkv, Ks, Vs, bt, tok0, L, head, hidden, maxL, qic, qf, oacc);
     const float inv = 1.0f / ltot;
+    if constexpr (BLK) {
+        // ctx in the blocked layout (preblk_elem, H = hidden; it is the O projection's A operand): lane (query fr, half fh)
+        // holds dims 32 mt + 8 g + 4 fh + {0..3}; the 16-byte piece (j = mt, lg = 2 (g & 1) + fh) of its token pairs g and
+        // g + 2.  Straight from the registers: 16 lanes (16 consecutive tokens) write 256 contiguous bytes.
+        if (qi < L) {
+            const int t_ = tok0 + qi;
+            bf16_t* cp = ctx + (size_t)(t_ >> 4) * (preblk_rowstride(hidden) / 2) + (size_t)head * 1024 + (t_ & 15) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int gl = 0; gl < 2; ++gl) {
+                    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                    v4u_ o;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int g = gl + 2 * h2;
+                        o[2 * h2] = (unsigned)f2bf(oacc[mt][4 * g + 0] * inv) | ((unsigned)f2bf(oacc[mt][4 * g + 1] * inv) << 16);
+                        o[2 * h2 + 1] = (unsigned)f2bf(oacc[mt][4 * g + 2] * inv) | ((unsigned)f2bf(oacc[mt][4 * g + 3] * inv) << 16);
+                    }
+                    *reinterpret_cast<v4u_*>(cp + mt * 512 + (2 * gl + fh) * 128) = o;
+                }
+        }
+        return;
+    }
     // Output rows leave through a per-wave LDS transpose (the K / V tiles are dead: the pass ends with a block
     // barrier): a lane owns HALF a query row in 8-byte pieces, so direct stores scatter 8-B pieces over 64 rows per
     // instruction (store-issue bound: a quarter of a block's life in round 2); after the transpose 8 lanes write one

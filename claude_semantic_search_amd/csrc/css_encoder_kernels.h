@@ -1564,7 +1564,10 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
                 const bool first = lrun + __shfl_xor(lrun, 32) == 0.f;
                 if (!__all(mloc <= 0.f && !first)) {
                     const float d = first ? mloc : fmaxf(mloc, 0.f);
-                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    // (first tile: the running sums are still 0 and are not rescaled -- with d = a hugely NEGATIVE lone
+                    // maximum, e.g. a one-token sequence whose only logit is -1e4, exp2(-d) is inf and 0 * inf poisoned
+                    // the row with NaN; later tiles have d >= 0, alpha <= 1)
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-d);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] -= d;
                     mrun += d;

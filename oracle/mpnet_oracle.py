@@ -95,6 +95,40 @@ def synth_weights(cfg: MpnetCfg, seed: int) -> Dict[str, torch.Tensor]:
     return w
 
 
+def trained_like_weights(cfg: MpnetCfg, seed: int, outlier_dims: Sequence[int] = (7, 77, 300, 511, 640, 767),
+                         gamma_gain: float = 4.0, emb_gain: float = 4.0, logit_gain: float = 1.5,
+                         ffn_bias_gain: float = 10.0) -> Dict[str, torch.Tensor]:
+    """``synth_weights`` reshaped towards the statistics of a TRAINED encoder, which N(0, 0.02^2) weights lack: a handful
+    of hidden dimensions carry outlier magnitudes through the whole residual stream (LayerNorm gamma x ``gamma_gain``
+    with alternating signs and beta +-3 on ``outlier_dims`` in EVERY LayerNorm, embedding columns x ``emb_gain``), attention
+    logits are ``logit_gain`` x larger (q and k weights and biases x sqrt(gain): peaked softmax rows), and one FFN unit in
+    twenty has a bias ``ffn_bias_gain`` x the others' (units that sit far inside GELU's linear or zero region).  This is
+    the regime in which a bf16 residual stream with fixed-point row statistics is most exposed.
+    Defaults (measured on the fp32 oracle, 12 layers): outlier channels ~33 x the mean |activation| behind every
+    LayerNorm, attention logits of std 6-8 and |max| ~30 (a trained model's range).  The gains compound: 6 / 6 / 1.5 give
+    outliers of ~64 x and logits up to ~70, 30 / 20 / 6 logits of +-7000 -- far outside any trained model, for overflow
+    tests only."""
+    w = synth_weights(cfg, seed)
+    d = torch.tensor(list(outlier_dims), dtype=torch.long)
+    sign = torch.tensor([1.0 if i % 2 == 0 else -1.0 for i in range(len(outlier_dims))])
+    w["embeddings.word_embeddings.weight"][:, d] *= emb_gain
+    w["embeddings.word_embeddings.weight"][cfg.pad_id] = 0
+    ln_names = ["embeddings.LayerNorm"]
+    for i in range(cfg.num_layers):
+        ln_names += [f"encoder.layer.{i}.attention.LayerNorm", f"encoder.layer.{i}.output.LayerNorm"]
+    for nm in ln_names:
+        w[nm + ".weight"][d] *= gamma_gain * sign
+        w[nm + ".bias"][d] += 3.0 * sign
+    g = math.sqrt(logit_gain)
+    for i in range(cfg.num_layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("q", "k"):
+            w[p + f"attention.attn.{nm}.weight"] *= g
+            w[p + f"attention.attn.{nm}.bias"] *= g
+        w[p + "intermediate.dense.bias"][::20] *= ffn_bias_gain
+    return w
+
+
 def relative_position_bucket(rel: torch.Tensor, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
     """modeling_mpnet.py:326-348 (rel = key position - query position)."""
     ret = 0

@@ -414,3 +414,107 @@ def test_attention_reference_free_pass_and_its_guard(qk_gain):
         q0, k0 = qkv[:129, :64], qkv[:129, 768:768 + 64]      # sequence of 129 tokens, head 0 (q pre-scaled to log2 units)
         assert np.abs(q0 @ k0.T).max() > 110
     enc.close()
+
+
+def test_trained_like_outlier_statistics_keep_the_bf16_paths_inside_the_tolerance():
+    """every other encoder test draws its weights from N(0, 0.02^2).  A trained MPNet has outlier
+    channels (a few hidden dimensions with LayerNorm gains and activations tens of times the others'), peaked softmax
+    rows and FFN units deep inside GELU's tails -- the regime the bf16 residual stream with fixed-point row statistics
+    (the LayerNorm-folded path of batches >= 1024 tokens) is most exposed to.  ``mpnet_oracle.trained_like_weights``
+    builds such weights; 256 chunks of mixed lengths go through the folded path and (in slices) through the small-batch
+    bf16 path, and both are held against the fp32 oracle: cosine >= 1 - 1e-3 per row AND pairwise-score drift <= 1e-3
+    over the whole 256 x 256 score matrix -- the north-star's tolerance on what a search actually ranks by.
+    Measured (tools/enc_drift_probe.py, one MI355X, 12 layers, drift = max over the 65 536 pairs): default gains 4 / 4 /
+    1.5 (outlier channels ~33 x the mean activation, logits up to ~30): folded path 5.4e-4, small-batch path 5.6e-4;
+    gains 6 / 6 / 1.5 (outliers ~64 x): 1.5e-3 / 2.1e-3 -- there the bf16 MFMA operands themselves exceed 1e-3, the
+    fp32-residual small-batch path no less than the bf16-residual folded one; plain N(0, 0.02^2) weights: 2e-5 / 8e-6."""
+    from claude_semantic_search_amd import synth
+    from oracle import mpnet_oracle as mo
+
+    cfg = mo.MpnetCfg(num_layers=12)
+    w = mo.trained_like_weights(cfg, 33)
+    chars = 100 + synth.uint(5, np.arange(256, dtype=np.uint64), 0, 1901)
+    lengths = np.clip(np.round(chars / 10).astype(np.int64) + 2, 2, 384).tolist()      # mean ~ 107 tokens, 27 k tokens in all
+    lengths[0], lengths[1], lengths[2] = 384, 1, 383
+    batch = mo.synth_batch(cfg, lengths, seed=6)
+    ref = mo.encode_batched(w, cfg, batch, batch_size=16)
+    # the outlier channels really dominate the oracle's residual stream (otherwise this test is the ordinary one)
+    probes = {}
+    with torch_no_grad():
+        mo.encode_tokens(w, cfg, batch[3], probes=probes)
+    a = probes["attn_out"].abs()
+    assert float(a[:, [7, 77, 300]].mean()) > 10 * float(a.mean())
+    enc = MpnetEncoder(synthetic_seed=33, compute="bf16")
+    enc.load_state_dict({k: v.numpy() for k, v in w.items()})
+    folded = enc.encode_ids(batch)                                         # one call: the LayerNorm-folded path
+    small = np.concatenate([enc.encode_ids(batch[i:i + 4]) for i in range(0, 64, 4)])   # <= 1024-token calls: the other bf16 path
+    enc.close()
+    for name, got, r in (("folded", folded, ref), ("small batches", small, ref[:64])):
+        assert np.isfinite(got).all(), name
+        cos = (got * r).sum(1)
+        assert cos.min() > 1 - 1e-3, (name, float(cos.min()))
+        drift = np.abs(got @ got.T - r @ r.T).max()
+        assert drift <= 1e-3, (name, float(drift), float(cos.min()))
+
+
+def test_huge_lone_logits_do_not_poison_the_running_maximum_pass():
+    """Found by the test above with extreme gains: a one-token sequence whose only attention logit is hugely negative
+    (-1e4 in the log2 domain) takes the running-maximum pass (exp2 underflows in the fast pass), whose first-tile
+    rescale multiplied the still-zero sums by exp2(+1e4) = inf -> NaN for the whole row.  With attention logits of
+    +-7000 (gains 30 / 20 / 6) every output must be finite, and rows whose softmax is trivially exact -- one-token
+    sequences: the single probability is 1 whatever the logit -- must still match the fp32 oracle."""
+    from oracle import mpnet_oracle as mo
+
+    cfg = mo.MpnetCfg(num_layers=3)
+    w = mo.trained_like_weights(cfg, 34, gamma_gain=30.0, emb_gain=20.0, logit_gain=6.0)
+    lengths = [1] * 40 + [384, 200, 77, 384, 300]             # 1385 tokens: the folded path; the ones alone: the small path
+    batch = mo.synth_batch(cfg, lengths, seed=8)
+    ref = mo.encode(w, cfg, batch[:40])
+    enc = MpnetEncoder(synthetic_seed=34, compute="bf16", cfg_overrides={"num_layers": 3})
+    enc.load_state_dict({k: v.numpy() for k, v in w.items()})
+    folded = enc.encode_ids(batch)
+    small = enc.encode_ids(batch[:40])
+    enc.close()
+    assert np.isfinite(folded).all() and np.isfinite(small).all()
+    assert (folded[:40] * ref).sum(1).min() > 1 - 1e-3 and (small * ref).sum(1).min() > 1 - 1e-3
+
+
+def torch_no_grad():
+    import torch
+
+    return torch.no_grad()
+
+
+def test_real_checkpoint_directory_matches_transformers_when_one_is_supplied():
+    """Opt-in (``CSS_REAL_MODEL_DIR`` = a local all-mpnet-base-v2 directory in sentence-transformers / HF layout; skipped
+    when unset: no checkpoint exists offline): the user's own weights and vocabulary through ``MpnetEncoder`` -- loader,
+    WordPiece front end, HIP encoder -- against ``transformers.AutoTokenizer`` / ``AutoModel`` + mean pooling + normalise,
+    the pipeline ``SentenceTransformer.encode(..., normalize_embeddings=True)`` runs (``src/embeddings.py:86-88, :216-222``).
+    Nothing from the reference or from the checkpoint is copied anywhere."""
+    import os
+
+    d = os.environ.get("CSS_REAL_MODEL_DIR")
+    if not d:
+        pytest.skip("CSS_REAL_MODEL_DIR is not set (no all-mpnet-base-v2 checkpoint offline)")
+    import torch
+    import torch.nn.functional as F
+    from transformers import AutoModel, AutoTokenizer
+
+    texts = ["How do I configure the semantic search index?", "def add(a, b):\n    return a + b", "Résumé of the café meeting — naïve façade.",
+             "x", "The quick brown fox jumps over the lazy dog. " * 40]
+    sub = os.path.join(d, "0_Transformer") if os.path.isdir(os.path.join(d, "0_Transformer")) else d
+    tok = AutoTokenizer.from_pretrained(sub)
+    model = AutoModel.from_pretrained(sub).eval()
+    with torch.no_grad():
+        b = tok(texts, padding=True, truncation=True, max_length=384, return_tensors="pt")
+        h = model(**b).last_hidden_state
+        m = b["attention_mask"][:, :, None].float()
+        ref = F.normalize((h * m).sum(1) / m.sum(1).clamp(min=1e-9), p=2, dim=1).numpy()
+    for compute, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        enc = MpnetEncoder(d, compute=compute)
+        ids = enc.tokenize(texts)
+        want = [[t for t, a in zip(row, att) if a] for row, att in zip(b["input_ids"].tolist(), b["attention_mask"].tolist())]
+        assert [list(map(int, r)) for r in ids] == want                   # the tokenizer front end, id for id
+        got = enc.encode(texts, batch_size=8, normalize_embeddings=True)
+        enc.close()
+        assert np.abs(got - ref).max() < tol and (got * ref).sum(1).min() > 1 - 1e-3, compute

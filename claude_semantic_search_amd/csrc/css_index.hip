@@ -1348,7 +1348,7 @@ bool want_shadow(css_index* ix, int64_t ncap) {
         return (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : -1);
     }();
     const int policy = ix->shadow_policy >= 0 ? ix->shadow_policy : env_policy;
-    if (policy == 0) return false;
+    if (policy == 0 || policy == 2) return false;   // (2: int8 rows only, want_i8_only)
     if (policy == 1) return true;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
@@ -1367,6 +1367,25 @@ bool want_i8(css_index* ix, int64_t ncap) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
     return (double)ncap * ix->dpad * 7.0 <= 0.8 * (double)tot;
+}
+
+// int8 rows WITHOUT bf16 rows (5 bytes per element): shards of ~38-46 M rows of 768 floats on a 288 GB GPU, where fp32 +
+// bf16 rows no longer fit in 80 % of the HBM but fp32 + int8 rows do -- such an index otherwise re-converts its rows into
+// scratch memory on every batched search (6.7 ms per 10 M rows).  Only where the int8 scan and sweep apply (inner
+// product, rows a whole number of 256-element K-step pairs, at most 1024 elements); css_index_set_shadow(ix, 2) forces
+// it (tests), policy 0 forbids every shadow copy.
+bool want_i8_only(css_index* ix, int64_t ncap) {
+    static const bool env_on = [] {
+        const char* e = getenv("CSS_KNN_I8");
+        return !(e && e[0] == '0');
+    }();
+    if (!env_on || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || ix->dpad > 1024) return false;
+    if (ix->shadow_policy == 0) return false;
+    if (ix->shadow_policy == 2) return true;
+    if (ix->shadow_policy == 1) return false;   // "always bf16" that did not fit: nothing
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    return (double)ncap * ix->dpad * 5.0 <= 0.8 * (double)tot;
 }
 
 // (Re)allocate the row storage for exactly ncap rows, carrying the ntotal existing rows over.
@@ -1393,7 +1412,8 @@ int reallocate_rows(css_index* ix, int64_t ncap) {
     // the int8 rows of the few-query sweep ride along with the bf16 ones when 7 bytes per element still fit
     unsigned char* nx8 = nullptr;
     float* nx8s = nullptr;
-    if (nxh && (ix->x8 != nullptr || ix->ntotal == 0) && want_i8(ix, ncap)) {
+    const bool i8_only = !nxh && ((ix->x8 != nullptr && ix->xh == nullptr) || ix->ntotal == 0) && want_i8_only(ix, ncap);
+    if ((nxh && (ix->x8 != nullptr || ix->ntotal == 0) && want_i8(ix, ncap)) || i8_only) {
         if (hipMalloc((void**)&nx8, ((size_t)ncap + 256) * ix->dpad) != hipSuccess ||
             hipMalloc((void**)&nx8s, ((size_t)ncap + 256) * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();
@@ -1907,11 +1927,6 @@ inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     // and the int8 search still wins: 10 M rows in 20 000 clusters, 33 flagged: 12.8 ms against 13.3 on bf16 rows)
     return i8_feedback_allows(ix->fb_batch, 50);
 }
-inline bool batch_uses_i8(css_index* ix, int k, int64_t nq) {
-    if (ix->x8 == nullptr) return false;
-    if (ix->xh == nullptr) return true;   // a shadow-less range converted to int8 scratch rows: the choice was made there
-    return batch_i8_wanted(ix, k, ix->ntotal, nq);
-}
 
 template <int NQ>
 int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t count, int64_t stride, int gm1, bool stage0,
@@ -1936,8 +1951,11 @@ inline int coarse_max_chunk(const css_index* ix) { return std::min(4096, coarse_
 
 // sweep = true: 1..4 queries through the HBM-bound bf16 sweep (k_sweep_coarse) instead of the MFMA scan.
 // Everything is enqueued on `st`; nothing waits for the device (flagged queries are fixed up on the device).
+// use_i8: which shadow rows this SEARCH reads, decided once by the caller (search_dev_enqueue / search_noshadow_ranges:
+// the per-index feedback is consulted once per search, not per chunk); record_fb: this is the search's last chunk, whose
+// flagged count is what the feedback sees.
 int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st,
-                       const SweepGeom& sg, bool sweep) {
+                       const SweepGeom& sg, bool sweep, bool use_i8, bool record_fb) {
     const KnnEnv& env = knn_env();
     const float* qpad = ix->qpad + (size_t)q0 * ix->dpad;
     const float* qnorm2 = ix->qnorm2 + q0;
@@ -1947,7 +1965,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)
-    const bool i8 = sweep ? sweep_uses_i8(ix) : batch_uses_i8(ix, k, nq);
+    const bool i8 = use_i8;
     const float i8_rel = sqrtf((float)ix->dpad) / 254.f;
     const float eps_rel = i8 ? (sweep ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
                              : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
@@ -2128,9 +2146,9 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         CSS_LAUNCH_CHECK();
     }
     }
-    // feedback for batch_uses_i8 / sweep_uses_i8 (the last chunk of a search speaks for it)
-    if (i8b && env.batch_i8 == 1 && (rc = i8_feedback_record(ix->fb_batch, nflag, nq, st)) != CSS_OK) return rc;
-    if (i8 && sweep && (rc = i8_feedback_record(ix->fb_sweep, nflag, nq, st)) != CSS_OK) return rc;
+    // feedback for batch_i8_wanted / sweep_uses_i8: the last chunk of a search speaks for it
+    if (record_fb && i8b && env.batch_i8 == 1 && (rc = i8_feedback_record(ix->fb_batch, nflag, nq, st)) != CSS_OK) return rc;
+    if (record_fb && i8 && sweep && (rc = i8_feedback_record(ix->fb_sweep, nflag, nq, st)) != CSS_OK) return rc;
     if (pass2) {
         // every launch below reads the flagged count from device memory and returns at once when there is nothing to do
         ProfScope ps("knn_coarse_pass2", st);
@@ -2245,21 +2263,25 @@ int merge_parts(const float* Dp, const int64_t* Ip, int nparts, int64_t stride_d
 // rows are exactly the shadow rows it would have had), and the per-range top-k lists are merged.  Per 10 M rows:
 // 46 GB of conversion traffic + the 13.6 ms cascade, against 45-48 ms for the split-operand scan it replaces (three
 // MFMA products per score, 4.4 x its algorithmic bytes), and the cost of the conversion is shared by up to 4096
-// queries.  Returns CSS_ERR_STATE without touching the outputs when no scratch of at least 2^20 rows can be had.
-int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st) {
+// queries.  Returns kNoRangeScratch without touching the outputs (nothing enqueued) when no scratch of at least 2^20 rows can be had.
+// (internal, never crosses the C ABI: "no scratch memory for the row ranges -- take the fallback"; distinct from every
+// css_status so that an error of an inner launch can never be mistaken for it)
+constexpr int kNoRangeScratch = 1;
+int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st, bool allow_i8) {
     int rc;
     const int64_t ntotal = ix->ntotal;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CSS_ERR_STATE;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return kNoRangeScratch;
     const size_t row_b = (size_t)ix->dpad * 2;
     int64_t rows_fit = (int64_t)((free_b + ix->xh_tmp_cap * 2) / 2 / row_b);          // half of what is free (incl. our own scratch)
     rows_fit = std::min<int64_t>(rows_fit, 16ll << 20) / CZ_T * CZ_T;
     int64_t S = std::min<int64_t>((ntotal + CZ_T - 1) / CZ_T * CZ_T, rows_fit);
-    if (S < std::min<int64_t>(ntotal, 1ll << 20)) return CSS_ERR_STATE;
+    if (S < std::min<int64_t>(ntotal, 1ll << 20)) return kNoRangeScratch;
     if (ix->range_rows > 0) S = std::min<int64_t>(S, (ix->range_rows + CZ_T - 1) / CZ_T * CZ_T);
     // int8 scratch rows where the int8 scan pays (38 GB of conversion traffic per 10 M rows instead of 46, half the scan):
     // same quantiser as k_ingest_rows, whose running maximum of the int8 error norms covers every row of the index
-    const bool use_i8 = batch_i8_wanted(ix, k, std::min<int64_t>(S, ntotal), nq);
+    // (allow_i8 = false: an index with int8 rows of its own whose int8 choice was already declined for this search)
+    const bool use_i8 = allow_i8 && batch_i8_wanted(ix, k, std::min<int64_t>(S, ntotal), nq);
     if (use_i8 && (rc = grow(&ix->x8s_tmp, &ix->x8s_tmp_cap, (size_t)S + 256)) != CSS_OK) return rc;
     if ((size_t)S * ix->dpad > ix->xh_tmp_cap) {   // (exact size: grow() would double a multi-GB buffer)
         if (ix->xh_tmp) CSS_HIP_TRY(hipFree(ix->xh_tmp));
@@ -2267,7 +2289,7 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
         ix->xh_tmp_cap = 0;
         if (hipMalloc((void**)&ix->xh_tmp, (size_t)S * row_b) != hipSuccess) {
             (void)hipGetLastError();
-            return CSS_ERR_STATE;
+            return kNoRangeScratch;
         }
         ix->xh_tmp_cap = (size_t)S * ix->dpad;
     }
@@ -2282,8 +2304,14 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
             ix->rng_d = nullptr;
             ix->rng_i = nullptr;
             ix->rng_cap = 0;
-            CSS_HIP_TRY(hipMalloc((void**)&ix->rng_d, need * sizeof(float)));
-            CSS_HIP_TRY(hipMalloc((void**)&ix->rng_i, need * sizeof(int64_t)));
+            if (hipMalloc((void**)&ix->rng_d, need * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&ix->rng_i, need * sizeof(int64_t)) != hipSuccess) {   // (nothing enqueued yet: the fallback is safe)
+                (void)hipGetLastError();
+                if (ix->rng_d) (void)hipFree(ix->rng_d);
+                ix->rng_d = nullptr;
+                ix->rng_i = nullptr;
+                return kNoRangeScratch;
+            }
             ix->rng_cap = need;
         }
     }
@@ -2320,7 +2348,8 @@ int search_noshadow_ranges(css_index* ix, int64_t nq, int k, float* D_dev, int64
         const int chunk = coarse_max_chunk(ix);
         for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
             const int nqc = (int)std::min<int64_t>(chunk, nq - q0);
-            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, Dp, Ip, st, sg, false)) != CSS_OK) return rc;
+            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, Dp, Ip, st, sg, false, use_i8,
+                                         r == nranges - 1 && q0 + nqc == nq)) != CSS_OK) return rc;
         }
     }
     if (nranges > 1)
@@ -2390,21 +2419,28 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     const bool coarse_pays = nq > 4 || k > 32 || ix->ntotal >= 100000;
     const bool want_split = mode == CSS_SEARCH_SPLIT || env.batch == 1;   // split-operand candidate scan from the fp32 rows
     const bool want_candidates = env.batch == 0 && (mode == CSS_SEARCH_COARSE || (mode == CSS_SEARCH_AUTO && coarse_pays));
-    if (want_candidates && ix->xh != nullptr) {
-        if (nq <= 4)  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
-            return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true);
-        const int chunk = coarse_max_chunk(ix);
-        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-            const int nqc = (int)std::min<int64_t>(chunk, nq - q0);
-            if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, sg, false)) != CSS_OK) return rc;
+    // Which shadow rows this search reads is decided HERE, once (the per-index int8 feedback counts searches, not chunks).
+    // An index with int8 rows only takes the candidate path where the int8 rows are chosen; otherwise it goes on like an
+    // index without shadow rows (bf16 scratch ranges for batches, the exact kernels for a few queries).
+    if (want_candidates && (ix->xh != nullptr || ix->x8 != nullptr)) {
+        const bool sweep = nq <= 4;  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
+        const bool use_i8 = ix->x8 != nullptr && (sweep ? sweep_uses_i8(ix) : batch_i8_wanted(ix, k, ix->ntotal, nq));
+        if (use_i8 || ix->xh != nullptr) {
+            if (sweep) return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true, use_i8, true);
+            const int chunk = coarse_max_chunk(ix);
+            for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+                const int nqc = (int)std::min<int64_t>(chunk, nq - q0);
+                if ((rc = launch_scan_coarse(ix, (int)q0, nqc, k, D_dev, I_dev, st, sg, false, use_i8, q0 + nqc == nq)) != CSS_OK)
+                    return rc;
+            }
+            return CSS_OK;
         }
-        return CSS_OK;
     }
     // no shadow rows: batches take the same cascade over bf16 rows rounded on the fly, one row range at a time
     // (CSS_KNN_NOSHADOW=split, a k beyond the MFMA kernels, or no HBM left for the scratch rows: the split-operand scan)
     if (want_candidates && ix->xh == nullptr && nq > 16 && env.noshadow_ranges && ix->dpad % 128 == 0) {
-        rc = search_noshadow_ranges(ix, nq, k, D_dev, I_dev, st);
-        if (rc != CSS_ERR_STATE) return rc;
+        rc = search_noshadow_ranges(ix, nq, k, D_dev, I_dev, st, ix->x8 == nullptr);
+        if (rc != kNoRangeScratch) return rc;
     }
     if (batch_ok && k + kSplitExtra <= kMfmaMaxK && (want_split || (want_candidates && ix->xh == nullptr))) {
         for (int64_t q0 = 0; q0 < nq; q0 += 4096) {   // (chunked like the bf16 cascade: candidate buffers are per query)
@@ -2607,7 +2643,7 @@ int css_index_shadow_info(css_index* ix, int* has_bf16, int* has_int8) {
 
 int css_index_set_shadow(css_index* ix, int policy) {
     CSS_REQUIRE(ix, "css_index_set_shadow: NULL index");
-    CSS_REQUIRE(policy >= -1 && policy <= 1, "css_index_set_shadow: policy %d outside {-1, 0, 1}", policy);
+    CSS_REQUIRE(policy >= -1 && policy <= 2, "css_index_set_shadow: policy %d outside {-1, 0, 1, 2}", policy);
     std::unique_lock<std::shared_mutex> lk(ix->mu);
     if (ix->ntotal != 0) {
         css::set_error("css_index_set_shadow: the index already holds %lld rows (set the policy on an empty index)",

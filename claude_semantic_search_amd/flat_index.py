@@ -170,10 +170,12 @@ class IndexFlat:
         nat.check(nat.lib().css_index_shadow_info(self._handle(), ctypes.byref(a), ctypes.byref(b)))
         return {"bf16": bool(a.value), "int8": bool(b.value)}
 
-    def set_shadow(self, policy: Optional[bool]) -> None:
-        """bf16 shadow rows (operand of the candidate scans, +50 % HBM): ``None`` = keep them while they
-        fit (default), ``False`` = never, ``True`` = always.  Only on an empty index; results do not change."""
-        p = -1 if policy is None else (1 if policy else 0)
+    def set_shadow(self, policy) -> None:
+        """Reduced-precision copies of the rows (operands of the candidate scans): ``None`` = automatic (bf16 + int8
+        rows while 7 bytes per element fit in 80 % of the HBM, bf16 only at 6, int8 ONLY at 5 -- shards of ~38-46 M
+        rows of 768 floats), ``False`` = never, ``True`` = always bf16, ``"int8"`` = int8 rows only.  Only on an empty
+        index; results do not change."""
+        p = -1 if policy is None else (2 if policy == "int8" else (1 if policy else 0))
         nat.check(nat.lib().css_index_set_shadow(self._handle(), p))
 
     def set_range_rows(self, rows: int) -> None:

@@ -90,12 +90,17 @@ int css_index_last_flagged(css_index* ix, int64_t* n);
 /* ... and how many of those the second coarse pass could not settle either (candidate buffers of 32768 rows
  * overflowed, or more than 1024 flagged queries in a chunk): these were re-run by the exact fp32 sweep. */
 int css_index_last_swept(css_index* ix, int64_t* n);
-/* bf16 shadow rows (the operand of the candidate scans; +50 % HBM next to the fp32 rows): -1 = keep them
- * while fp32 + bf16 rows fit in 80 % of the HBM (default), 0 = never, 1 = always.  Only on an empty index.
- * Results do not depend on it: without shadow rows batches form their candidate scores from the fp32 rows.
- * Where 7 bytes per element still fit (and rows have at most 1024 elements) the index also keeps INT8 rows
- * (signed byte = round(x / s), s = max|x| / 127 per row; +25 %), which searches of 1..4 queries sweep instead
- * of the bf16 rows: half the bytes, candidates inside the error band measured at ingest, same exact results. */
+/* Reduced-precision copies of the rows, the operands of the candidate scans (results never depend on them: candidates
+ * come from a scan inside an error band measured at ingest and are rescored in fp32):
+ *   bf16 rows (+50 % HBM next to the fp32 rows) and INT8 rows (signed byte = round(x / s), s = max|x| / 127 per row;
+ *   +25 %; rows of at most 1024 elements).  Searches of 1..4 queries sweep the int8 rows; batches scan them with int8
+ *   MFMA where that pays (inner product, rows a multiple of 256 elements: k <= 32 from 300 k rows, k <= 128 from 4 M rows
+ *   with >= 256 queries; an index whose int8 searches flag more than 5 % of their queries falls back to the bf16 rows
+ *   for the next 16 searches), otherwise the bf16 rows.
+ * policy: -1 = automatic -- both copies while 7 bytes per element fit in 80 % of the HBM, bf16 only at 6 bytes, INT8 ONLY
+ * at 5 bytes (inner product, rows a multiple of 256 elements: ~38-46 M rows of 768 floats on a 288 GB GPU), nothing
+ * beyond (batches then round row ranges into scratch memory per search); 0 = never any copy; 1 = always bf16 (+ int8
+ * while it fits); 2 = int8 rows only.  Only on an empty index. */
 int css_index_set_shadow(css_index* ix, int policy);
 /* Diagnostics: which reduced-precision copies of the rows the index currently holds (0 / 1 each). */
 int css_index_shadow_info(css_index* ix, int* has_bf16, int* has_int8);
@@ -122,7 +127,9 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * error band and return exact fp32 scores of the rescored candidates (same
  * results as the fp32 kernels).  Without shadow rows, batches round the rows to
  * bf16 one row range at a time into scratch memory and run the same scan per range.  The _dev form only enqueues on `stream` and never
- * waits for the device: queries whose candidate band overflows are re-run exactly by
+ * waits for the device (one exception: the FIRST batched search of an index without shadow rows allocates that scratch
+ * -- up to half of the free HBM -- and a growing workspace is reallocated; hipMalloc / hipFree synchronise the device.
+ * Later searches of the same shapes allocate nothing): queries whose candidate band overflows are re-run exactly by
  * two launches that follow every cascade and return at once when there are none.
  * Rows appended by css_index_add_dev / css_index_add_synthetic on another stream are
  * ordered before the search by an event (no caller-side synchronisation needed); successive

@@ -291,6 +291,72 @@ def test_int8_rows_follow_growth_reset_and_shadow_policy():
     ns.close()
 
 
+def test_int8_only_shadow_rows_every_query_shape_matches_the_oracle():
+    """An index that keeps int8 rows but NO bf16 rows (what a 38-46 M-row shard of 768 floats gets automatically: 5 bytes
+    per element fit in 80 % of the HBM, 6 do not; forced here with set_shadow("int8")): single queries sweep the int8 rows,
+    batches scan them with int8 MFMA, flagged queries (no bf16 rows for a second pass) go to the exact sweep; shapes the
+    int8 scan does not serve -- k beyond its select's range, an int8 choice the feedback has backed off -- take the bf16
+    scratch ranges / exact kernels of a shadow-less index.  Rows follow reallocation and reset; masks, duplicates floods
+    and k > 128 included; same answers as the oracle throughout."""
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    ix = IndexFlatIP(768)
+    ix.set_shadow("int8")
+    ref = ko.FlatIndexOracle(768)
+    q = ko.normalize_rows(synth.rows(300, 768, 710))
+    for step, n in enumerate([900, 6000, 30000]):          # reallocations carry the int8 rows over
+        x = synth.rows(n, 768, 720 + step)
+        if step == 2:
+            x[5000:9000] = x[4999]                            # a duplicate flood: band overflow -> exact sweep (no second pass)
+        ix.add(x, normalize=True)
+        ref.add(ko.normalize_rows(x))
+        assert ix.shadow_info() == {"bf16": False, "int8": True}
+    qq = np.concatenate([q, ref._xb[4999:5000] + 0.01 * q[:1]])     # ... and a query inside the flood
+    for mode in ("coarse", "auto", "exact_fp32"):
+        ix.set_search_mode(mode)
+        for nq, k in ((1, 10), (1, 100), (3, 10), (40, 10), (301, 10), (301, 100), (2, 300)):
+            D, I = ix.search(qq[-nq:], k)
+            Dr, Ir = ref.search(qq[-nq:], k)
+            assert_topk_matches(D, I, Dr, Ir, ref.rescore64(qq[-nq:], Ir), f"int8-only [{mode}] nq={nq} k={k}")
+    ix.set_search_mode("coarse")
+    allow = (np.arange(ix.ntotal) % 4) != 2
+    sub = np.flatnonzero(allow)
+    o2 = ko.FlatIndexOracle(768)
+    o2.add(ref._xb[sub])
+    for nq in (1, 64):
+        D, I = ix.search(q[:nq], 10, allow=allow)
+        Dr, Ir = o2.search(q[:nq], 10)
+        assert_topk_matches(D, I, Dr, sub[Ir], o2.rescore64(q[:nq], Ir), f"int8-only masked nq={nq}")
+    ix.reset()
+    x = synth.rows(4000, 768, 730)
+    ix.add(x, normalize=True)
+    assert ix.shadow_info() == {"bf16": False, "int8": True}
+    r2 = ko.FlatIndexOracle(768)
+    r2.add(ko.normalize_rows(x))
+    D, I = ix.search(q[:5], 10)
+    Dr, Ir = r2.search(q[:5], 10)
+    assert_topk_matches(D, I, Dr, Ir, r2.rescore64(q[:5], Ir), "int8-only after reset")
+    ix.close()
+    # from 300 k rows on batches with k <= 32 take the int8 MFMA scan by themselves
+    big = IndexFlatIP(768)
+    big.set_shadow("int8")
+    big.add_synthetic(320_000, seed=740, first_row=0, normalize=True)
+    rb = ko.FlatIndexOracle(768)
+    rb.add(ko.normalize_rows(ko.synth_rows(320_000, 768, 740)))
+    for nq in (64, 1):
+        D, I = big.search(q[:nq], 10)
+        Dr, Ir = rb.search(q[:nq], 10)
+        assert_topk_matches(D, I, Dr, Ir, rb.rescore64(q[:nq], Ir), f"int8-only 320 k rows nq={nq}")
+    assert big.shadow_info() == {"bf16": False, "int8": True}
+    big.close()
+    l2 = __import__("claude_semantic_search_amd.flat_index", fromlist=["x"]).IndexFlatL2(768)
+    l2.set_shadow("int8")                                      # squared L2 has no int8 scan: no copy at all
+    l2.add(x)
+    assert l2.shadow_info() == {"bf16": False, "int8": False}
+    l2.close()
+
+
 def test_id_base_and_merge_parts_match_whole():
     """Row-partitioned shards + merge == one index, on one GPU."""
     import ctypes

@@ -929,7 +929,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 // step the cursor keeps re-reading the last tile: harmless -- the slot it lands in is never read again -- and it
 // keeps the issue free of branches)
 #define G8_ISSUE(KIND_, DB_)                                                                                  \
-    {                                                                                                         \
+    if (!(G8_ABL & 4)) {                                                                                      \
         const char* base_ = reinterpret_cast<const char*>(((KIND_) == G8_A0 || (KIND_) == G8_A1) ? A : W);    \
         const bool ablk_ = ABLK && ((KIND_) == G8_A0 || (KIND_) == G8_A1);   /* (blocked: K step = next 2-KiB block, half j = 1 follows) */ \
         const unsigned o0_ = srco[KIND_] + (unsigned)it_kt[KIND_] * (ablk_ ? 2048u : 128u);                   \
@@ -1007,19 +1007,39 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     const int a_o0 = ABLK ? wr * 8192 + lane * 16 : swz_byte(wr * 64 + lq, lg), a_o1 = ABLK ? a_o0 + 1024 : (a_o0 ^ 64);
     const int b_o0 = swz_byte(wc * 32 + lq, lg), b_o1 = b_o0 ^ 64;
     v4f a[4][2], b0[2][2], b1[2][2];
+    if (G8_ABL & 2) {   // (ablation build: the fragments are never read from LDS -- opaque non-zero register contents instead)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a[j][c] = v4f{1.25f, -0.75f, 0.5f, 2.0f};
+                asm volatile("" : "+v"(a[j][c]));
+            }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                b0[n][c] = v4f{0.3f, 1.5f, -0.9f, 0.7f};
+                b1[n][c] = v4f{-1.1f, 0.2f, 0.6f, 1.3f};
+                asm volatile("" : "+v"(b0[n][c]), "+v"(b1[n][c]));
+            }
+    }
 #define G8_READ_A(S_, D_)                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+    if (!(G8_ABL & 2)) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
         a[j][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_A1 : G8_A0)) * G8_HT + j * 2048 + a_o0); \
         a[j][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_A1 : G8_A0)) * G8_HT + j * 2048 + a_o1); \
     }
 #define G8_READ_B(S_, D_, B_)                                                                                 \
-    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                           \
+    if (!(G8_ABL & 2)) _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                        \
         B_[n][0] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_B1 : G8_B0)) * G8_HT + n * 2048 + b_o0); \
         B_[n][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_B1 : G8_B0)) * G8_HT + n * 2048 + b_o1); \
     }
 // transposed product (MFMA rows <- W rows, columns <- tokens): a lane owns one token row and 4 consecutive columns
+#ifndef G8_ABL
+#define G8_ABL 0
+#endif
 #define G8_MFMA(MH_, NH_, B_)                                                                                 \
-    {                                                                                                         \
+    if (!(G8_ABL & 1)) {                                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                        \
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \

@@ -338,12 +338,12 @@ int launch_gemm_t(const void* A, const void* W, const float* bias, void* C, int 
 }
 
 // k_gemm8p launch (256x256 tiles, persistent, one block per CU); `side` carries the LayerNorm-folding operands
-template <int EPI, bool ABLK = false>
+template <int EPI, bool ABLK = false, int TAG = 0>
 int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
                   float qscale, const G8Side& side, int num_cus, hipStream_t st, const char* prof) {
     CSS_REQUIRE(N % 256 == 0 && K % 128 == 0 && (size_t)M * K * 2 < ((size_t)1 << 32), "gemm8p: bad shape %d x %d x %d", M, N, K);
     CSS_REQUIRE(EPI != EPI_RES || K >= 256, "gemm8p: EPI_RES needs K >= 256 (statistics are flushed in a tile's third K step)");
-    auto kern = k_gemm8p<EPI, ABLK>;
+    auto kern = k_gemm8p<EPI, ABLK, TAG>;
     constexpr size_t lds = 2 * 4 * G8_HT;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
@@ -528,7 +528,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.cvec = g_in;
         side.cgroup = enc_env().cg_o;
         side.grid = enc_env().grid_o;
-        if ((rc = launch_gemm8p<EPI_RES, true>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
+        if ((rc = launch_gemm8p<EPI_RES, true, 1>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
         side.stats_in = e->stats[1];

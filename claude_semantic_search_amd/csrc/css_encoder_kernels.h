@@ -851,7 +851,8 @@ constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
 // `bias`: the bias row (EPI_QKV / EPI_GELU), bias + beta of the residual's LayerNorm (EPI_RES) or the d row (EPI_AFF_*)
 // ABLK: the A operand is in the blocked layout (a pre tensor, or the FFN1 output read by FFN2); the output is written
 // in the blocked layout by EPI_RES (pre tensors) and EPI_AFF_GELU (the FFN1 output, whose only reader is FFN2's A side).
-template <int EPI, bool ABLK>
+// TAG only names the instantiation (rocprofv3 then lists the O projection, <EPI_RES, true, 1>, apart from FFN2, <EPI_RES, true, 0>).
+template <int EPI, bool ABLK, int TAG = 0>
 __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                 const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
                                                 int K, int qscale_cols, float qscale, G8Side side) {

@@ -845,6 +845,11 @@ struct G8Side {
 #else
 #define G8_SIDE_WAVES 6
 #endif
+// -DG8_ABL=<bits>: timing ablations of the main loop (results invalid): 1 no MFMAs, 2 no LDS fragment reads, 4 no LDS-DMA
+// issue (profiles/r04_gemm_loop_ablations.txt).  The product build has none of them.
+#ifndef G8_ABL
+#define G8_ABL 0
+#endif
 constexpr int G8_HT = 16384;
 constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
 
@@ -1036,9 +1041,6 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
         B_[n][1] = *reinterpret_cast<const v4f*>(smem + ((D_) * 4 + ((S_) ? G8_B1 : G8_B0)) * G8_HT + n * 2048 + b_o1); \
     }
 // transposed product (MFMA rows <- W rows, columns <- tokens): a lane owns one token row and 4 consecutive columns
-#ifndef G8_ABL
-#define G8_ABL 0
-#endif
 #define G8_MFMA(MH_, NH_, B_)                                                                                 \
     if (!(G8_ABL & 1)) {                                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                        \

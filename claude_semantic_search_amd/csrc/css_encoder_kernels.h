@@ -1514,8 +1514,32 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
         *reinterpret_cast<v4f*>(Ks + (BUF) * 8192 + swz_byte(srow + 32 * i, schunk)) = rk[i];       \
         *reinterpret_cast<v4f*>(Vs + (BUF) * 8192 + (BLK ? vblk_byte(srow + 32 * i, schunk) : vswz_byte(srow + 32 * i, schunk))) = rv[i]; \
     }
-    AT_GLOAD(0)
-    AT_SSTORE(0)
+    // BLK: K / V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write): a tile is 4 key blocks x 2 KiB per
+    // operand, wave w copies key block w in two 1-KiB pieces (4 pieces of 16 keys each).  The K tile is the block image
+    // itself ([key block][piece cl][key]: a K fragment read is 16 lanes x 16 B contiguous, conflict free); the V tile is
+    // the image with the keys of piece row lg rotated by 4 lg (vblk_byte): lane i of a piece fetches key (i & 15) ^ 4 lg.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#define AT_DMA(KT_, BUF)                                                                            \
+    _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                              \
+        const int cl_ = 4 * jp + (lane >> 4);                                                       \
+        const unsigned po_ = (unsigned)((cl_ >> 2) * 512 + (cl_ & 3) * 128);                        \
+        int kk_ = (KT_) * 64 + 16 * wv + (lane & 15);                                               \
+        int kv_ = (KT_) * 64 + 16 * wv + ((lane & 15) ^ ((cl_ & 3) << 2));                          \
+        kk_ = kk_ < L ? kk_ : L - 1;                                                                \
+        kv_ = kv_ < L ? kv_ : L - 1;                                                                \
+        const unsigned tk_ = (unsigned)(tok0 + kk_), tv_ = (unsigned)(tok0 + kv_);                  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kblk + ((tk_ >> 4) * brs + (tk_ & 15u) * 8u + po_)), \
+            (__attribute__((address_space(3))) void*)(Ks + (BUF) * 8192 + wv * 2048 + jp * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vblk + ((tv_ >> 4) * brs + (tv_ & 15u) * 8u + po_)), \
+            (__attribute__((address_space(3))) void*)(Vs + (BUF) * 8192 + wv * 2048 + jp * 1024), 16, 0, 0); \
+    }
+    if constexpr (BLK) {
+        AT_DMA(0, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        AT_GLOAD(0)
+        AT_SSTORE(0)
+    }
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1535,7 +1559,11 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
     for (int kt = 0; kt < nkt; ++kt) {
 #if !defined(ATT_DBG) || !(ATT_DBG & (1 | 128))
         if (kt + 1 < nkt) {
-            AT_GLOAD(kt + 1)
+            if constexpr (BLK) {
+                AT_DMA(kt + 1, cur ^ 1)   // (buffer cur ^ 1 was last read in tile kt - 1, behind that tile's barrier)
+            } else {
+                AT_GLOAD(kt + 1)
+            }
         }
 #endif
         const char* Kb = Ks + cur * 8192;
@@ -1570,7 +1598,8 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
 #if !defined(ATT_DBG) || !(ATT_DBG & 32)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const v4f kf = *reinterpret_cast<const v4f*>(Kb + swz_byte(sub * 32 + fr, 2 * ks + fh));
+                const v4f kf = *reinterpret_cast<const v4f*>(Kb + (BLK ? (2 * sub + (fr >> 4)) * 2048 + (2 * ks + fh) * 256 + (fr & 15) * 16
+                                                                       : swz_byte(sub * 32 + fr, 2 * ks + fh)));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[ks]), s, 0, 0, 0);
             }
 #endif
@@ -1648,7 +1677,9 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
             }
         }
 #if !defined(ATT_DBG) || !(ATT_DBG & (16 | 128))
-        if (kt + 1 < nkt) {
+        if constexpr (BLK) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
+        } else if (kt + 1 < nkt) {
             AT_SSTORE(cur ^ 1)
         }
         __syncthreads();
@@ -1659,6 +1690,7 @@ __device__ __forceinline__ float attn_pass(const bf16_t* __restrict__ qkv, char*
     }
 #undef AT_GLOAD
 #undef AT_SSTORE
+#undef AT_DMA
     return lrun + __shfl_xor(lrun, 32);
 }
 

@@ -32,13 +32,18 @@ while time.time() - t0 < secs:
     elif kind == "wide_norms":
         x = x * np.exp(rng.normal(0, 0.7, size=(n, 1))).astype(np.float32)
     nq = int(rng.choice([1, 2, 4, 7, 16, 40, 255, 256, 700]))
-    k = int(rng.choice([1, 10, 100]))
+    k = int(rng.choice([1, 10, 100, 100, 129, 300, 700]))     # > 128: passes of 128 over the rows not returned yet
+    if k > 128 and nq > 7:
+        nq = int(rng.choice([1, 2, 5]))                        # (k > 128 goes query by query)
     q = synth.rows(nq, d, seed + 2)
     if kind in ("clustered", "dups") and nq > 1:
         q[: nq // 2] = x[rng.integers(0, n, size=nq // 2)] + 0.01 * q[: nq // 2]
     allow = (rng.random(n) < 0.6) if rng.random() < 0.25 else None
     ix = IndexFlat(d, metric)
     noshadow = rng.random() < 0.2
+    i8only = (not noshadow) and metric == 0 and d % 256 == 0 and rng.random() < 0.3
+    if i8only:
+        ix.set_shadow("int8")  # int8 rows without bf16 rows: int8 sweep / scan, else bf16 scratch ranges / exact kernels
     if noshadow:
         ix.set_shadow(0)      # batches: bf16 rows rounded range by range into scratch memory ("coarse"), or split operands ("split")
         ix.set_range_rows(int(rng.choice([0, 0, 4096, 33_000])))
@@ -48,7 +53,7 @@ while time.time() - t0 < secs:
         ix.set_search_mode(mode)
         res[mode] = ix.search(q, k, normalize=norm, allow=allow) if allow is not None else ix.search(q, k, normalize=norm)
     De, Ie = res["exact_fp32"]
-    tag0 = f"it={it} d={d} n={n} metric={metric} norm={norm} kind={kind} nq={nq} k={k} masked={allow is not None} noshadow={noshadow} seed={seed}"
+    tag0 = f"it={it} d={d} n={n} metric={metric} norm={norm} kind={kind} nq={nq} k={k} masked={allow is not None} noshadow={noshadow} i8only={i8only} seed={seed}"
     valid = Ie >= 0
     scale = max(1.0, float(np.abs(De[valid]).max())) if valid.any() else 1.0
     gaps = np.abs(np.diff(De.astype(np.float64), axis=1))

@@ -497,7 +497,7 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
     bf16_t* pre[2] = {(bf16_t*)e->x16, (bf16_t*)e->pre32};
     {
         ProfScope ps("enc_embed_ln", st);
-        hipLaunchKernelGGL(k_embed_pre<768>, dim3((T + 3) / 4), dim3(256), 0, st, ids, cu, B, e->wemb, e->pemb, c.vocab,
+        hipLaunchKernelGGL(k_embed_pre<768>, dim3((T + 15) / 16), dim3(256), 0, st, ids, cu, B, e->wemb, e->pemb, c.vocab,
                            c.max_pos, pre[0], e->stats[0], T, kStatScale1, kStatScale2);
         CSS_LAUNCH_CHECK();
     }

@@ -133,37 +133,58 @@ __global__ __launch_bounds__(256) void k_embed_pre(const int32_t* __restrict__ i
                                                    const float* __restrict__ pemb, int vocab, int max_pos,
                                                    bf16_t* __restrict__ pre, long long* __restrict__ stats, int T,
                                                    float scale1, float scale2) {
-    constexpr int NV = H / 256;
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
-    int lo = 0, hi = B;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cu[mid] <= t) lo = mid; else hi = mid;
-    }
-    int id = ids[t];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    int pos = (t - cu[lo]) + 2;
-    pos = pos < max_pos ? pos : max_pos - 1;
-    const float4* w4 = reinterpret_cast<const float4*>(wemb + (size_t)id * H);
-    const float4* p4 = reinterpret_cast<const float4*>(pemb + (size_t)pos * H);
+    // One block = one 16-token block row of the blocked layout: thread (lq = tid & 15, g = tid >> 4) writes the 16-byte
+    // pieces g, g + 16, ... of token lq, so 16 consecutive lanes store 256 contiguous bytes (one piece row of a block).
+    static_assert(H % 64 == 0, "blocked layout");
+    constexpr int NP = H / 8;   // 16-byte pieces per token row
+    __shared__ float red[2][16][17];
+    const int lq = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + lq;
     float s1 = 0.f, s2 = 0.f;
+    if (t < T) {
+        int lo = 0, hi = B;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cu[mid] <= t) lo = mid; else hi = mid;
+        }
+        int id = ids[t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        int pos = (t - cu[lo]) + 2;
+        pos = pos < max_pos ? pos : max_pos - 1;
+        const float* wr_ = wemb + (size_t)id * H;
+        const float* pr_ = pemb + (size_t)pos * H;
+        char* orow = reinterpret_cast<char*>(pre) + (size_t)(t >> 4) * preblk_rowstride(H) + lq * 16;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float4 a = w4[lane + 64 * i], b = p4[lane + 64 * i];
-        ushort4 h;
-        h.x = f2bf(a.x + b.x); h.y = f2bf(a.y + b.y); h.z = f2bf(a.z + b.z); h.w = f2bf(a.w + b.w);
-        *reinterpret_cast<ushort4*>(pre + preblk_elem(t, 4 * (lane + 64 * i), H)) = h;   // (4 columns = one 8-byte half piece)
-        const float x = bf2f(h.x), y = bf2f(h.y), z = bf2f(h.z), w = bf2f(h.w);
-        s1 += (x + y) + (z + w);
-        s2 += (x * x + y * y) + (z * z + w * w);
+        for (int pi = g; pi < NP; pi += 16) {
+            const int cb = pi >> 3, j = (pi >> 2) & 1, lg = pi & 3;
+            const int c0 = 64 * cb + 32 * j + 4 * lg;
+            const float4 a0 = *reinterpret_cast<const float4*>(wr_ + c0), a1 = *reinterpret_cast<const float4*>(wr_ + c0 + 16);
+            const float4 b0 = *reinterpret_cast<const float4*>(pr_ + c0), b1 = *reinterpret_cast<const float4*>(pr_ + c0 + 16);
+            const float v[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16_t h0 = f2bf(v[2 * e]), h1 = f2bf(v[2 * e + 1]);
+                o[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                const float x = bf2f(h0), y = bf2f(h1);   // statistics of the STORED values
+                s1 += x + y;
+                s2 += x * x + y * y;
+            }
+            *reinterpret_cast<uint4*>(orow + (size_t)cb * 2048 + j * 1024 + lg * 256) = uint4{o[0], o[1], o[2], o[3]};
+        }
     }
-    s1 = wave_allsum(s1);
-    s2 = wave_allsum(s2);
-    if (lane == 0) {
-        stats[(size_t)t * 2] = __float2ll_rn(s1 * scale1);
-        stats[(size_t)t * 2 + 1] = __float2ll_rn(s2 * scale2);
+    red[0][g][lq] = s1;
+    red[1][g][lq] = s2;
+    __syncthreads();
+    if (g == 0 && t < T) {   // fixed summation order: a forward pass stays bit reproducible
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a += red[0][i][lq];
+            b += red[1][i][lq];
+        }
+        stats[(size_t)t * 2] = __float2ll_rn(a * scale1);
+        stats[(size_t)t * 2 + 1] = __float2ll_rn(b * scale2);
     }
 }
 
@@ -1887,28 +1908,58 @@ __global__ __launch_bounds__(256) void k_pool_partial_ln(const bf16_t* __restric
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float inv_h, float eps, const int32_t* __restrict__ cu, int S,
                                                          float* __restrict__ part) {
+    // Blocked layout (preblk_elem): thread (lq = tid & 15, g = tid >> 4) reads the 16-byte pieces g, g + 16, ... of the
+    // tokens t with t % 16 == lq, so 16 consecutive lanes read 256 contiguous bytes; the 16 token classes are summed in a
+    // fixed order at the end.
+    static_assert(H % 128 == 0, "6 pieces per thread");
+    constexpr int NP = H / 8, PT = NP / 16;   // pieces per token row / per thread
+    __shared__ float red[16][H + 8];
     const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int lq = tid & 15, g = tid >> 4;
     const int t0 = cu[b], L = cu[b + 1] - t0;
     const int per = (L + S - 1) / S;
     const int lo = min(L, sl * per), hi = min(L, lo + per);
-    constexpr int PER = (H + 255) / 256;
-    float acc[PER];
+    float acc[PT][8];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
-    for (int t = lo; t < hi; ++t) {
-        const v4u32 raw = *reinterpret_cast<const v4u32*>(stats + (size_t)(t0 + t) * 2);
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    const int tb = t0 + lo, te = t0 + hi;
+    for (int t = (tb & ~15) + lq; t < te; t += 16) {
+        if (t < tb) continue;
+        const v4u32 raw = *reinterpret_cast<const v4u32*>(stats + (size_t)t * 2);
         float rs, mrs;
         row_stats_decode(raw, inv_h, eps, rs, mrs);
+        const char* row = reinterpret_cast<const char*>(pre) + (size_t)(t >> 4) * preblk_rowstride(H) + lq * 16;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int c = tid + 256 * i;
-            if (c < H) acc[i] += fmaf(bf2f(pre[preblk_elem(t0 + t, c, H)]), rs, -mrs);   // (blocked layout, see k_embed_pre)
+        for (int i = 0; i < PT; ++i) {
+            const int pi = g + 16 * i;
+            const uint4 w = *reinterpret_cast<const uint4*>(row + (size_t)(pi >> 3) * 2048 + ((pi >> 2) & 1) * 1024 + (pi & 3) * 256);
+            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[i][2 * e] += fmaf(__uint_as_float(ww[e] << 16), rs, -mrs);
+                acc[i][2 * e + 1] += fmaf(__uint_as_float(ww[e] & 0xFFFF0000u), rs, -mrs);
+            }
         }
     }
+    // piece pi holds columns 64 cb + 32 j + 4 lg + {0..3} and the same + 16
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + 256 * i;
-        if (c < H) part[((size_t)b * S + sl) * H + c] = fmaf(acc[i], gamma[c], (float)(hi - lo) * beta[c]);
+    for (int i = 0; i < PT; ++i) {
+        const int pi = g + 16 * i;
+        const int c0 = 64 * (pi >> 3) + 32 * ((pi >> 2) & 1) + 4 * (pi & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[lq][c0 + e] = acc[i][e];
+            red[lq][c0 + 16 + e] = acc[i][4 + e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < H; c += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i][c];
+        part[((size_t)b * S + sl) * H + c] = fmaf(a, gamma[c], (float)(hi - lo) * beta[c]);
     }
 }
 

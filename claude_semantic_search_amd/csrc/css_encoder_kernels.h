@@ -116,6 +116,11 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
 #define CSS_PREBLK_PAD 0
 #endif
 __host__ __device__ __forceinline__ size_t preblk_rowstride(int H) { return (size_t)(H >> 6) * 2048 + CSS_PREBLK_PAD; }
+// G8_BBLK: the WEIGHTS of the GEMMs with blocked A operands are stored in the blocked layout too ([N][K] through
+// preblk_elem: contiguous 1-KiB DMA pieces, fragment reads without a swizzle; 0: row-major with the K order permuted)
+#ifndef G8_BBLK
+#define G8_BBLK 1
+#endif
 __device__ __forceinline__ size_t preblk_elem(int t, int c, int H) {   // element index of (token t, column c)
     return ((size_t)(t >> 4) * preblk_rowstride(H) + (size_t)(c >> 6) * 2048) / 2 + ((c >> 5) & 1) * 512 + ((c & 15) >> 2) * 128 +
            (t & 15) * 8 + ((c >> 4) & 1) * 4 + (c & 3);
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, co
     c = wave_allsum(c) / (float)K;
     d = wave_allsum(d);
     // perm: the A operand is a pre tensor in the blocked layout, whose K order inside a 64-column block is permuted
-    for (int k = lane; k < K; k += 64) Wf[(size_t)j * K + (perm ? preblk_kpos(k) : k)] = f2bf(fmaf(W[(size_t)j * K + k], gamma[k], -c));
+    for (int k = lane; k < K; k += 64)
+        Wf[perm ? (G8_BBLK ? preblk_elem(j, k, K) : (size_t)j * K + preblk_kpos(k)) : (size_t)j * K + k] = f2bf(fmaf(W[(size_t)j * K + k], gamma[k], -c));
     if (lane == 0) dvec[j] = d + bias[j];
 }
 
@@ -871,6 +877,7 @@ struct G8Side {
 #ifndef G8_ABL
 #define G8_ABL 0
 #endif
+
 constexpr int G8_HT = 16384;
 constexpr int G8_A0 = 0, G8_B0 = 1, G8_B1 = 2, G8_A1 = 3;
 
@@ -948,6 +955,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
             /* stand (two 1-KiB pieces, source and LDS destination both contiguous): lane = piece (lg, lq) of half j  */ \
             srco[KIND_] = (unsigned)((r0_ + wr * 128 + ((KIND_) == G8_A1 ? 64 : 0) + wc * 16) >> 4) * (unsigned)preblk_rowstride(K) + \
                           (unsigned)lane * 16u;                                                               \
+        } else if (ABLK && G8_BBLK) {   /* weights stored blocked as well (preblk_elem over [N][K]): wave w copies block row */ \
+            srco[KIND_] = (unsigned)((c0_ + (wave >> 1) * 64 + ((KIND_) == G8_B1 ? 32 : 0) + 16 * (wave & 1)) >> 4) * \
+                          (unsigned)preblk_rowstride(K) + (unsigned)lane * 16u;                               \
         } else {                                                                                              \
             srco[KIND_] = (unsigned)grow_ * (unsigned)K * 2u + ((pchunk ^ ((srow_ >> 1) & 7)) << 4);          \
         }                                                                                                     \
@@ -958,7 +968,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 #define G8_ISSUE(KIND_, DB_)                                                                                  \
     if (!(G8_ABL & 4)) {                                                                                      \
         const char* base_ = reinterpret_cast<const char*>(((KIND_) == G8_A0 || (KIND_) == G8_A1) ? A : W);    \
-        const bool ablk_ = ABLK && ((KIND_) == G8_A0 || (KIND_) == G8_A1);   /* (blocked: K step = next 2-KiB block, half j = 1 follows) */ \
+        const bool ablk_ = ABLK && (G8_BBLK || (KIND_) == G8_A0 || (KIND_) == G8_A1);   /* (blocked: K step = next 2-KiB block, half j = 1 follows) */ \
         const unsigned o0_ = srco[KIND_] + (unsigned)it_kt[KIND_] * (ablk_ ? 2048u : 128u);                   \
         const unsigned o1_ = ablk_ ? (o0_ + 1024u) : ((o0_ + row8) ^ 64u);                                    \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o0_),        \
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
     // (ABLK: the A slot holds the blocked image itself -- block (wr, j) at (wr * 4 + j) * 2048, piece (c, lg, lq) of it at
     // c * 1024 + lane * 16: a fragment read is 1 KiB of contiguous LDS, conflict free without a swizzle)
     const int a_o0 = ABLK ? wr * 8192 + lane * 16 : swz_byte(wr * 64 + lq, lg), a_o1 = ABLK ? a_o0 + 1024 : (a_o0 ^ 64);
-    const int b_o0 = swz_byte(wc * 32 + lq, lg), b_o1 = b_o0 ^ 64;
+    const int b_o0 = (ABLK && G8_BBLK) ? wc * 4096 + lane * 16 : swz_byte(wc * 32 + lq, lg), b_o1 = (ABLK && G8_BBLK) ? b_o0 + 1024 : (b_o0 ^ 64);
     v4f a[4][2], b0[2][2], b1[2][2];
     if (G8_ABL & 2) {   // (ablation build: the fragments are never read from LDS -- opaque non-zero register contents instead)
 #pragma unroll
@@ -2002,7 +2012,7 @@ __global__ void k_f32_to_bf16_kperm(const float* __restrict__ in, bf16_t* __rest
     for (; i < n; i += stride) {
         const size_t row = i / (size_t)K;
         const int k = (int)(i - row * (size_t)K);
-        out[row * (size_t)K + preblk_kpos(k)] = f2bf(in[i]);
+        out[G8_BBLK ? preblk_elem((int)row, k, K) : row * (size_t)K + preblk_kpos(k)] = f2bf(in[i]);
     }
 }
 

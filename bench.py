@@ -847,11 +847,17 @@ def _main(argv, platform_factory):
             fence()
             dt = (time.perf_counter() - t0) / reps
             nat.prof_enable(False)
-            ms, n = nat.prof_read("knn_sweep_coarse_main")
             info = index.shadow_info() if hasattr(index, "shadow_info") else {"int8": False}
             i8 = bool(info.get("int8")) and os.environ.get("CSS_KNN_SWEEP", "") != "bf16"
             row_b = args.dim * (1 if i8 else 2) + (4 if i8 else 0)   # int8 rows + their fp32 scale, or bf16 rows
-            if n:   # coarse sweep over the int8 (or bf16) shadow rows: main stage = the row tiles t with t % g != 0 (g = 4)
+            ms, n = nat.prof_read("knn_sweep_fused")
+            fused = bool(n)
+            if not fused:
+                ms, n = nat.prof_read("knn_sweep_coarse_main")
+            if fused:   # the whole cascade (every stage and the selects between them) is ONE launch over all shadow rows
+                kbytes = shard * row_b
+                kname = "k_sweep_cascade<1, 3, true>" if i8 else "k_sweep_cascade<1, 6, false>"
+            elif n:   # coarse sweep over the int8 (or bf16) shadow rows: main stage = the row tiles t with t % g != 0 (g = 4)
                 ntiles = -(-shard // 256)
                 main_rows = min(((ntiles - 1) - (ntiles - 1) // SWEEP_GROWTH) * 256, shard)
                 kbytes = main_rows * row_b
@@ -863,7 +869,7 @@ def _main(argv, platform_factory):
             gbs = kbytes / (ms / n / 1e3) / 1e9 if n else None
             cms, cn = nat.prof_read("knn_sweep_cascade")
             tr = pmc_traffic(kname, wl)
-            rec = {"bound": "hbm", "kernel": kname + " (main stage of the single-query cascade)", "achieved": gbs,
+            rec = {"bound": "hbm", "kernel": kname + (" (the single-query cascade in one launch)" if fused else " (main stage of the single-query cascade)"), "achieved": gbs,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS if gbs else None,
                    "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": kbytes,
                    "latency_ms": dt * 1e3, "cascade_ms": cms / cn if cn else None, "scan_kernel_ms": ms / n if n else None,

@@ -93,6 +93,7 @@ struct css_index {
     float* cand_s = nullptr;  size_t cand_s_cap = 0;
     uint32_t* cand_i = nullptr; size_t cand_i_cap = 0;
     int* cpace = nullptr;     size_t cpace_cap = 0;     // sibling pacing counters [stage][group]
+    int* fs_state = nullptr;  size_t fs_state_cap = 0;  // k_sweep_cascade: ticket / stage counters / threshold key words
     // device-side exact fix-up of flagged queries (k_scan_small<FIX>): one global list + lock per query
     float* fix_s = nullptr;   uint32_t* fix_i = nullptr; size_t fix_cap = 0;    // entries [nq_pad][k]
     int* fix_lock = nullptr;  size_t fix_lock_cap = 0;
@@ -1512,6 +1513,7 @@ struct KnnEnv {
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
+    int sweep_fused = 0;    // CSS_KNN_SWEEP_FUSED=1: k_sweep_cascade (one launch) instead of one launch per stage and select of that cascade
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
@@ -1535,6 +1537,7 @@ const KnnEnv& knn_env() {
             const int v = atoi(m);
             e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 4;
         }
+        if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
@@ -1804,7 +1807,7 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
         CSS_HIP_TRY(hipMemsetAsync(qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, gthr, nq_pad, host_f2key(-INFINITY));
     hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags, nflag,
-                       nq, nq_pad, 0, (int*)nullptr, 0, (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
+                       nq, nq_pad, 0, (int*)nullptr, 0, (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (int*)nullptr);
     const int64_t ne = (int64_t)nq_pad * ix->dpad;
     hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qsplit,
                        (int64_t)nq_pad, ix->dpad);
@@ -1944,6 +1947,37 @@ int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t cou
     return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
 }
 
+// the whole sweep cascade in one launch (k_sweep_cascade); sc: the schedule as tickets
+template <int NQ, int TT, bool I8>
+int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSched& sc, int* flags, const float* qnorm2,
+                           float eps_rel, int l2, int k, int measured, hipStream_t st) {
+    const int steps = I8 ? (TT > 0 ? TT : (ix->dpad / 16 + 15) / 16) : 0;
+    const size_t lds = (size_t)cz_fs_lds_floats(NQ, I8 ? 256 * steps : ix->dpad) * sizeof(float);
+    auto kern = k_sweep_cascade<NQ, TT, I8>;
+    int rc;
+    if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    // as many blocks as the chip holds at once (a block leaves only when the tickets run out: more would start at the
+    // very end, load the queries and find nothing to do); nothing depends on the blocks being co-resident
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * std::min(per_cu, 8), sc.first[sc.nstage]);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, I8 ? (const void*)ix->x8 : (const void*)ix->xh,
+                       I8 ? (const float*)ix->x8s : (const float*)nullptr, qpad, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
+                       flags, ix->ntotal, ix->dpad, nq, sc, ix->fs_state, ix->cur_mask,
+                       ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr, qnorm2, (const int*)ix->maxn2, eps_rel, l2, k, measured);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+template <int NQ>
+int launch_sweep_cascade_nq(css_index* ix, const float* qpad, int nq, const FsSched& sc, int* flags, const float* qnorm2,
+                            float eps_rel, int l2, int k, int measured, hipStream_t st, bool i8) {
+    if (i8)
+        return ix->dpad == 768 ? launch_sweep_cascade_t<NQ, 3, true>(ix, qpad, nq, sc, flags, qnorm2, eps_rel, l2, k, measured, st)
+                               : launch_sweep_cascade_t<NQ, 0, true>(ix, qpad, nq, sc, flags, qnorm2, eps_rel, l2, k, measured, st);
+    return ix->dpad == 768 ? launch_sweep_cascade_t<NQ, 6, false>(ix, qpad, nq, sc, flags, qnorm2, eps_rel, l2, k, measured, st)
+                           : launch_sweep_cascade_t<NQ, 0, false>(ix, qpad, nq, sc, flags, qnorm2, eps_rel, l2, k, measured, st);
+}
+
 // grid of the persistent k_scan_coarse launches and the largest query chunk it can serve: the nqt blocks
 // that share a row tile must fit the grid / 8 blocks of one XCD group (a CPX partition has few CUs)
 inline int coarse_grid(const css_index* ix) { return std::max(8, ix->num_cus / 8 * 8); }
@@ -2047,6 +2081,25 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
     }
     const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
+    // 1..4 queries: the stages and the selects between them as ONE launch (k_sweep_cascade), tiles as tickets in stage order
+    bool fused = sweep && env.sweep_fused && (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 30;
+    FsSched fsched{};
+    if (fused) {
+        fsched.nstage = (int)sched.size();
+        int64_t first = 0;
+        for (size_t si = 0; si < sched.size(); ++si) {
+            const int64_t W = (ntiles + sched[si].stride - 1) / sched[si].stride;
+            const int gr = si == 0 ? g : sched[si].ratio;
+            const int64_t count = si == 0 ? W : (W - 1) - (W - 1) / gr;
+            if (count <= 0) fused = false;   // (a stage without tiles would leave nobody to run its select; not seen with these schedules)
+            fsched.first[si] = (int)first;
+            fsched.stride[si] = (int)sched[si].stride;
+            fsched.gm1[si] = std::max(1, gr - 1);
+            first += count;
+        }
+        fsched.first[sched.size()] = (int)first;
+        if (fused && (rc = grow(&ix->fs_state, &ix->fs_state_cap, (size_t)CZ_FS_WORDS)) != CSS_OK) return rc;
+    }
     constexpr int kPaceGroups = 512, kPaceStages = 20;
     const bool use_pace = !sweep && env.pacing;
     if (use_pace && (rc = grow(&ix->cpace, &ix->cpace_cap, (size_t)kPaceGroups * kPaceStages)) != CSS_OK) return rc;
@@ -2065,10 +2118,11 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             CSS_LAUNCH_CHECK();
         }
         const int npace = use_pace ? kPaceGroups * kPaceStages : 0;
-        const int ninit = std::max(std::max(nq_pad, npace), f2);
+        const int ninit = std::max(std::max(std::max(nq_pad, npace), f2), fused ? CZ_FS_WORDS : 0);
         hipLaunchKernelGGL(k_coarse_init, dim3((ninit + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T), use_pace ? ix->cpace : (int*)nullptr, npace,
-                           pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2);
+                           pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2,
+                           fused ? ix->fs_state : (int*)nullptr);
         CSS_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
@@ -2106,7 +2160,19 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     CSS_REQUIRE(sweep || (grid / 8) / nqt >= 1, "css_index_search: %d query tiles do not fit a grid of %d blocks", nqt, grid);
 
     int stage_idx = 0;
-    {
+    if (fused) {
+        ProfScope all("knn_sweep_cascade", st);
+        {
+            ProfScope ps("knn_sweep_fused", st);
+            if (nq <= 1) rc = launch_sweep_cascade_nq<1>(ix, qpad, nq, fsched, flags, qnorm2, eps_rel, l2, k, measured, st, i8);
+            else if (nq <= 2) rc = launch_sweep_cascade_nq<2>(ix, qpad, nq, fsched, flags, qnorm2, eps_rel, l2, k, measured, st, i8);
+            else rc = launch_sweep_cascade_nq<4>(ix, qpad, nq, fsched, flags, qnorm2, eps_rel, l2, k, measured, st, i8);
+            if (rc != CSS_OK) return rc;
+        }
+        if ((rc = launch_final_select(ix, nq, k, EpsSet{eps_rel, qerr2, measured}, eps_p2, exact_k, l2, 0, qpad, qnorm2, ix->gthr + q0, flags, nflag, flag_list, D_dev,
+                                      I_dev, pass2 ? ix->thr2 : nullptr, pass2 ? ix->qh2 : nullptr, f2, st)) != CSS_OK)
+            return rc;
+    } else {
     ProfScope all(sweep ? "knn_sweep_cascade" : "knn_coarse_cascade", st);
     for (size_t si = 0; si < sched.size(); ++si) {
         const int64_t s = sched[si].stride;
@@ -2529,7 +2595,7 @@ int css_index_free(css_index* ix) {
         }
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
                     ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
-                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->mask_ws, ix->excl_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
+                    ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->fs_state, ix->mask_ws, ix->excl_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
                     ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->x8s_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)

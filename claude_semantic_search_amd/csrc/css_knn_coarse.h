@@ -142,14 +142,23 @@ constexpr int CZ_PARTS = 16;
 // returning device-scope atomics of the scan stages piling up on a few memory channels and measured no gain -- the
 // cost was in the hit loop of the tile epilogue, not in the atomics.
 constexpr int CZ_NS = 1;
+// k_sweep_cascade (the 1..4-query cascade in one launch, below): its limits and its state words
+constexpr int CZ_FS_MAXST = 16;            // stages (growth 4: 4^15 tiles)
+constexpr int CZ_FS_RING = 4;              // pending tiles per block
+constexpr int CZ_FS_SENT = 0x7FFFFFFF;     // key word "not published yet" (a NaN's key: a published threshold never is one)
+// state words (k_coarse_init): [0] next ticket | [1] abort | [2 + s] tiles of stage s appended | key of the threshold
+// that stage s applies to query q at [CZ_FS_KEY + 4 s + q]
+constexpr int CZ_FS_DONE = 2, CZ_FS_KEY = CZ_FS_DONE + CZ_FS_MAXST, CZ_FS_WORDS = CZ_FS_KEY + 4 * CZ_FS_MAXST;
 
 // thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
 // the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
 // flagged query claims take part in that scan with thr2 = +inf, i.e. without ever appending
 __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, int nq, int nq_pad, int n0rows,
                               int* __restrict__ pace, int npace, int* __restrict__ cand_n2, float* __restrict__ thr2,
-                              int* __restrict__ nflagB, int f2max) {
+                              int* __restrict__ nflagB, int f2max, int* __restrict__ fs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // k_sweep_cascade: counters zero, stage 0 open (threshold -inf), every later stage unpublished
+    if (fs != nullptr && i < CZ_FS_WORDS) fs[i] = i < CZ_FS_KEY ? 0 : (i < CZ_FS_KEY + 4 ? f2key(-INFINITY) : CZ_FS_SENT);
     if (i == 0) {
         *nflag = 0;
         if (nflagB) *nflagB = 0;
@@ -969,6 +978,141 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
 #undef CZ_TILE_OF
 }
 
+// One step of the bf16 sweep: rows ra_ / rb_ (clamped to the index) against the NQ queries in LDS; lane `sub` == j of
+// a row's 16 lanes gets query j's scores (ma: row ra_, mb: row rb_).  xn2 != null: L2 form 2 x.q - ||x||^2.
+template <int NQ, int TT>
+__device__ __forceinline__ void cz_sweep_pair_bf16(const unsigned short* __restrict__ xh, const float* qs, int64_t ra_, int64_t rb_,
+                                                   int dpad, int steps, int sub, const float* __restrict__ xn2, float& ma, float& mb) {
+    const uint4* pa = reinterpret_cast<const uint4*>(xh + (size_t)ra_ * dpad) + sub;
+    const uint4* pb = reinterpret_cast<const uint4*>(xh + (size_t)rb_ * dpad) + sub;
+    float sa[NQ], sb[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
+    if constexpr (TT > 0) {
+        uint4 va[TT], vb[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            va[t] = pa[16 * t];
+            vb[t] = pb[16 * t];
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const unsigned wa[4] = {va[t].x, va[t].y, va[t].z, va[t].w};
+            const unsigned wb[4] = {vb[t].x, vb[t].y, vb[t].z, vb[t].w};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float4 q0 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub);
+                const float4 q1 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub + 4);
+                const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
+                    sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
+                    sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
+                    sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
+                }
+            }
+        }
+    } else {
+        for (int t = 0; t < steps; ++t) {
+            if (128 * t + 8 * sub >= dpad) break;  // dpad is a multiple of 64: whole 16-B chunks
+            const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
+            const unsigned wa[4] = {xa.x, xa.y, xa.z, xa.w};
+            const unsigned wb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float* qv = qs + j * dpad + 128 * t + 8 * sub;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
+                    sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
+                    sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
+                    sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
+                }
+            }
+        }
+    }
+    float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
+    if (xn2 != nullptr) {
+        xa = xn2[ra_];
+        xb2 = xn2[rb_];
+    }
+    ma = mb = 0.f;  // score of query `sub` for this lane's row
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
+        if (sub == j) {
+            ma = xn2 != nullptr ? fmaf(2.f, ra, -xa) : ra;
+            mb = xn2 != nullptr ? fmaf(2.f, rb, -xb2) : rb;
+        }
+    }
+}
+
+// One step of the int8 sweep (layout and arithmetic: k_sweep_coarse_i8 below): rows ra_ / rb_ against the NQ permuted
+// queries in LDS (qlen floats each; my_off = 128 * sum of the query's elements for lane `sub`'s query).
+template <int NQ, int TT>
+__device__ __forceinline__ void cz_sweep_pair_i8(const unsigned char* __restrict__ x8, const float* __restrict__ x8s, const float* qs,
+                                                 int qlen, float my_off, int64_t ra_, int64_t rb_, int dpad, int chunks, int steps,
+                                                 int sub, const float* __restrict__ xn2, float& ma, float& mb) {
+    const uint4* pa = reinterpret_cast<const uint4*>(x8 + (size_t)ra_ * dpad) + sub;
+    const uint4* pb = reinterpret_cast<const uint4*>(x8 + (size_t)rb_ * dpad) + sub;
+    const float scA = x8s[ra_], scB = x8s[rb_];
+    float sa[NQ], sb[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
+#define CZ_I8_STEP(T_, VA_, VB_)                                                                              \
+    {                                                                                                  \
+        /* signed bytes -> offset binary (byte + 128) for v_cvt_f32_ubyte: one XOR per four elements */  \
+        const unsigned wa[4] = {(VA_).x ^ 0x80808080u, (VA_).y ^ 0x80808080u, (VA_).z ^ 0x80808080u, (VA_).w ^ 0x80808080u}; \
+        const unsigned wb[4] = {(VB_).x ^ 0x80808080u, (VB_).y ^ 0x80808080u, (VB_).z ^ 0x80808080u, (VB_).w ^ 0x80808080u}; \
+        _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                               \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                const float4 qv = *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
+                sa[j] = fmaf((float)(wa[r] & 0xFFu), qv.x, sa[j]);                                     \
+                sa[j] = fmaf((float)((wa[r] >> 8) & 0xFFu), qv.y, sa[j]);                              \
+                sa[j] = fmaf((float)((wa[r] >> 16) & 0xFFu), qv.z, sa[j]);                             \
+                sa[j] = fmaf((float)(wa[r] >> 24), qv.w, sa[j]);                                       \
+                sb[j] = fmaf((float)(wb[r] & 0xFFu), qv.x, sb[j]);                                     \
+                sb[j] = fmaf((float)((wb[r] >> 8) & 0xFFu), qv.y, sb[j]);                              \
+                sb[j] = fmaf((float)((wb[r] >> 16) & 0xFFu), qv.z, sb[j]);                             \
+                sb[j] = fmaf((float)(wb[r] >> 24), qv.w, sb[j]);                                       \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    if constexpr (TT > 0) {
+        uint4 va[TT], vb[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            va[t] = pa[16 * t];
+            vb[t] = pb[16 * t];
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) CZ_I8_STEP(t, va[t], vb[t])
+    } else {
+        for (int t = 0; t < steps; ++t) {
+            if (16 * t + sub >= chunks) break;
+            const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
+            CZ_I8_STEP(t, xa, xb4)
+        }
+    }
+#undef CZ_I8_STEP
+    float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
+    if (xn2 != nullptr) {
+        xa = xn2[ra_];
+        xb2 = xn2[rb_];
+    }
+    ma = mb = 0.f;  // score of query `sub` for this lane's row
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
+        if (sub == j) {
+            const float ca = scA * (ra - my_off), cb = scB * (rb - my_off);
+            ma = xn2 != nullptr ? fmaf(2.f, ca, -xa) : ca;
+            mb = xn2 != nullptr ? fmaf(2.f, cb, -xb2) : cb;
+        }
+    }
+}
+
 // The same cascade stage for 1..4 queries: an HBM-bound sweep over the bf16 shadow rows (half the bytes of the
 // fp32 sweep of k_scan_small).  16 lanes per row read 16 B each (8 bf16 = 256 B contiguous per row and column
 // step), the bf16 are widened to fp32 by a shift, multiplied with the fp32 query from LDS and reduced over the
@@ -997,69 +1141,9 @@ __global__ __launch_bounds__(256) void k_sweep_coarse(const unsigned short* __re
             // occupancy with them); one query stays in registers
             if constexpr (NQ > 1) asm volatile("" ::: "memory");
             const int64_t rowA = row_base + it * 4 + rg, rowB = rowA + 4;
-            const uint4* pa = reinterpret_cast<const uint4*>(xh + (size_t)(rowA < ntotal ? rowA : ntotal - 1) * dpad) + sub;
-            const uint4* pb = reinterpret_cast<const uint4*>(xh + (size_t)(rowB < ntotal ? rowB : ntotal - 1) * dpad) + sub;
-            float sa[NQ], sb[NQ];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
-            if constexpr (TT > 0) {
-                uint4 va[TT], vb[TT];
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    va[t] = pa[16 * t];
-                    vb[t] = pb[16 * t];
-                }
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    const unsigned wa[4] = {va[t].x, va[t].y, va[t].z, va[t].w};
-                    const unsigned wb[4] = {vb[t].x, vb[t].y, vb[t].z, vb[t].w};
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const float4 q0 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub);
-                        const float4 q1 = *reinterpret_cast<const float4*>(qs + j * dpad + 128 * t + 8 * sub + 4);
-                        const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
-                            sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
-                            sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
-                            sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
-                        }
-                    }
-                }
-            } else {
-                for (int t = 0; t < steps; ++t) {
-                    if (128 * t + 8 * sub >= dpad) break;  // dpad is a multiple of 64: whole 16-B chunks
-                    const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
-                    const unsigned wa[4] = {xa.x, xa.y, xa.z, xa.w};
-                    const unsigned wb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const float* qv = qs + j * dpad + 128 * t + 8 * sub;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            sa[j] = fmaf(__uint_as_float(wa[w] << 16), qv[2 * w], sa[j]);
-                            sa[j] = fmaf(__uint_as_float(wa[w] & 0xFFFF0000u), qv[2 * w + 1], sa[j]);
-                            sb[j] = fmaf(__uint_as_float(wb[w] << 16), qv[2 * w], sb[j]);
-                            sb[j] = fmaf(__uint_as_float(wb[w] & 0xFFFF0000u), qv[2 * w + 1], sb[j]);
-                        }
-                    }
-                }
-            }
-            float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
-            if (xn2 != nullptr) {
-                xa = xn2[rowA < ntotal ? rowA : ntotal - 1];
-                xb2 = xn2[rowB < ntotal ? rowB : ntotal - 1];
-            }
-            float ma = 0.f, mb = 0.f;  // score of query `sub` for this lane's row
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
-                if (sub == j) {
-                    ma = xn2 != nullptr ? fmaf(2.f, ra, -xa) : ra;
-                    mb = xn2 != nullptr ? fmaf(2.f, rb, -xb2) : rb;
-                }
-            }
+            float ma, mb;
+            cz_sweep_pair_bf16<NQ, TT>(xh, qs, rowA < ntotal ? rowA : ntotal - 1, rowB < ntotal ? rowB : ntotal - 1, dpad, steps, sub,
+                                       xn2, ma, mb);
             if (sub < nq) {
                 const bool okA = rowA < ntotal && CZ_ALLOWED(mask, rowA), okB = rowB < ntotal && CZ_ALLOWED(mask, rowB);
                 if (stage0) {
@@ -1135,64 +1219,9 @@ __global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __
         for (int it = 0; it < 16; it += 2) {
             if constexpr (NQ > 1) asm volatile("" ::: "memory");
             const int64_t rowA = row_base + it * 4 + rg, rowB = rowA + 4;
-            const int64_t ra_ = rowA < ntotal ? rowA : ntotal - 1, rb_ = rowB < ntotal ? rowB : ntotal - 1;
-            const uint4* pa = reinterpret_cast<const uint4*>(x8 + (size_t)ra_ * dpad) + sub;
-            const uint4* pb = reinterpret_cast<const uint4*>(x8 + (size_t)rb_ * dpad) + sub;
-            const float scA = x8s[ra_], scB = x8s[rb_];
-            float sa[NQ], sb[NQ];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) sa[j] = sb[j] = 0.f;
-#define CZ_I8_STEP(T_, VA_, VB_)                                                                              \
-            {                                                                                                  \
-                /* signed bytes -> offset binary (byte + 128) for v_cvt_f32_ubyte: one XOR per four elements */  \
-                const unsigned wa[4] = {(VA_).x ^ 0x80808080u, (VA_).y ^ 0x80808080u, (VA_).z ^ 0x80808080u, (VA_).w ^ 0x80808080u}; \
-                const unsigned wb[4] = {(VB_).x ^ 0x80808080u, (VB_).y ^ 0x80808080u, (VB_).z ^ 0x80808080u, (VB_).w ^ 0x80808080u}; \
-                _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                               \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
-                        const float4 qv = *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
-                        sa[j] = fmaf((float)(wa[r] & 0xFFu), qv.x, sa[j]);                                     \
-                        sa[j] = fmaf((float)((wa[r] >> 8) & 0xFFu), qv.y, sa[j]);                              \
-                        sa[j] = fmaf((float)((wa[r] >> 16) & 0xFFu), qv.z, sa[j]);                             \
-                        sa[j] = fmaf((float)(wa[r] >> 24), qv.w, sa[j]);                                       \
-                        sb[j] = fmaf((float)(wb[r] & 0xFFu), qv.x, sb[j]);                                     \
-                        sb[j] = fmaf((float)((wb[r] >> 8) & 0xFFu), qv.y, sb[j]);                              \
-                        sb[j] = fmaf((float)((wb[r] >> 16) & 0xFFu), qv.z, sb[j]);                             \
-                        sb[j] = fmaf((float)(wb[r] >> 24), qv.w, sb[j]);                                       \
-                    }                                                                                          \
-                }                                                                                              \
-            }
-            if constexpr (TT > 0) {
-                uint4 va[TT], vb[TT];
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    va[t] = pa[16 * t];
-                    vb[t] = pb[16 * t];
-                }
-#pragma unroll
-                for (int t = 0; t < TT; ++t) CZ_I8_STEP(t, va[t], vb[t])
-            } else {
-                for (int t = 0; t < steps; ++t) {
-                    if (16 * t + sub >= chunks) break;
-                    const uint4 xa = pa[16 * t], xb4 = pb[16 * t];
-                    CZ_I8_STEP(t, xa, xb4)
-                }
-            }
-#undef CZ_I8_STEP
-            float xa = 0.f, xb2 = 0.f;  // L2: ||row||^2 (score = 2 x.q - ||x||^2)
-            if (xn2 != nullptr) {
-                xa = xn2[ra_];
-                xb2 = xn2[rb_];
-            }
-            float ma = 0.f, mb = 0.f;  // score of query `sub` for this lane's row
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const float ra = row16_allsum(sa[j]), rb = row16_allsum(sb[j]);
-                if (sub == j) {
-                    const float ca = scA * (ra - my_off), cb = scB * (rb - my_off);
-                    ma = xn2 != nullptr ? fmaf(2.f, ca, -xa) : ca;
-                    mb = xn2 != nullptr ? fmaf(2.f, cb, -xb2) : cb;
-                }
-            }
+            float ma, mb;
+            cz_sweep_pair_i8<NQ, TT>(x8, x8s, qs, qlen, my_off, rowA < ntotal ? rowA : ntotal - 1, rowB < ntotal ? rowB : ntotal - 1,
+                                     dpad, chunks, steps, sub, xn2, ma, mb);
             if (sub < nq) {
                 const bool okA = rowA < ntotal && CZ_ALLOWED(mask, rowA), okB = rowB < ntotal && CZ_ALLOWED(mask, rowB);
                 if (stage0) {
@@ -1349,6 +1378,41 @@ constexpr int CZ_FLAGGED_RESCORE = 512;
 // coarse score and the entries above a threshold derived from it, not an ordering: the full bitonic sort they used
 // until round 3 (78 barrier-separated rounds at 4096 entries) was 15-35 us of every select and, with one block per
 // query, 0.35 ms of the 2.8 ms single-query search (7 selects in a row).  Block of 256 threads; hist: 256 words of LDS.
+// (one digit of that selection: hist holds the counts of the 256 digit values among the keys still in play; wave 0 finds the
+// bin of the kk-th largest and the number of keys in the bins above it -- sel[0], sel[1]; ends with a block barrier)
+__device__ __forceinline__ void cz_radix_pick(const unsigned* hist, int kk, int* sel, int tid) {
+    if (tid < 64) {   // lane l owns bins 255 - 4 l .. 252 - 4 l; cum = keys in its bins and all higher ones
+        const int b0 = 255 - 4 * tid;
+        const unsigned c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+        const unsigned tot = (c0 + c1) + (c2 + c3);
+        unsigned cum = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)cum, o);
+            if (tid >= o) cum += v;
+        }
+        const unsigned long long hit = __ballot(cum >= (unsigned)kk);   // (never empty: the candidates of this pass number >= kk)
+        if (tid == __ffsll((long long)hit) - 1) {
+            unsigned a = cum - tot;
+            int bsel = b0;
+            if (a + c0 < (unsigned)kk) {
+                a += c0;
+                bsel = b0 - 1;
+                if (a + c1 < (unsigned)kk) {
+                    a += c1;
+                    bsel = b0 - 2;
+                    if (a + c2 < (unsigned)kk) {
+                        a += c2;
+                        bsel = b0 - 3;
+                    }
+                }
+            }
+            sel[0] = bsel;
+            sel[1] = (int)a;
+        }
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ float cz_kth_largest(const float* s, int n, int k, unsigned* hist, int* sel, int tid) {
     unsigned prefix = 0, mask = 0;
     int kk = k;
@@ -1361,37 +1425,28 @@ __device__ __forceinline__ float cz_kth_largest(const float* s, int n, int k, un
             if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid < 64) {   // lane l owns bins 255 - 4 l .. 252 - 4 l; cum = keys in its bins and all higher ones
-            const int b0 = 255 - 4 * tid;
-            const unsigned c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
-            const unsigned tot = (c0 + c1) + (c2 + c3);
-            unsigned cum = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned v = (unsigned)__shfl_up((int)cum, o);
-                if (tid >= o) cum += v;
-            }
-            const unsigned long long hit = __ballot(cum >= (unsigned)kk);   // (never empty: the candidates of this pass number >= kk)
-            if (tid == __ffsll((long long)hit) - 1) {
-                unsigned a = cum - tot;
-                int bsel = b0;
-                if (a + c0 < (unsigned)kk) {
-                    a += c0;
-                    bsel = b0 - 1;
-                    if (a + c1 < (unsigned)kk) {
-                        a += c1;
-                        bsel = b0 - 2;
-                        if (a + c2 < (unsigned)kk) {
-                            a += c2;
-                            bsel = b0 - 3;
-                        }
-                    }
-                }
-                sel[0] = bsel;
-                sel[1] = (int)a;
-            }
-        }
+        cz_radix_pick(hist, kk, sel, tid);
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 0xFFu << shift;
+        kk -= sel[1];
         __syncthreads();
+    }
+    return key2f((int)(prefix ^ 0x80000000u));
+}
+// The same over keys held in registers: entry e of thread tid is candidate tid + 256 e, `live` bit e says it exists.
+template <int E>
+__device__ __forceinline__ float cz_kth_largest_regs(const unsigned (&key)[E], unsigned live, int k, unsigned* hist, int* sel, int tid) {
+    unsigned prefix = 0, mask = 0;
+    int kk = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (((live >> e) & 1u) && (key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        cz_radix_pick(hist, kk, sel, tid);
         prefix |= (unsigned)sel[0] << shift;
         mask |= 0xFFu << shift;
         kk -= sel[1];
@@ -1560,6 +1615,258 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
             flags[q] = fl;
         }
     }
+}
+
+// ------------------------------------------------------------------ the 1..4-query cascade in ONE launch
+// k_sweep_cascade runs every stage of the sweep cascade (the schedule of launch_scan_coarse) and the selects between
+// them in one persistent launch: 8 sweeps + 7 one-block selects at 10 M rows cost 0.25 ms of launch gaps, ramps and
+// tails on top of the bytes.  Row tiles are TICKETS in stage order (stage 0 first, the stride-1 stage last), drawn
+// from one counter by whichever block is free, so the stages pack without tails.  A block scores its tile into an LDS
+// ring of CZ_FS_RING pending tiles and tests a pending tile against its stage's thresholds once those are
+// published; the block whose tile is the last of stage s to be appended (counter of stage s) runs select(s) -- the
+// arithmetic of k_coarse_select<false> -- and publishes the thresholds of stage s + 1 as key words.
+// No wait can deadlock: a block waits only for the thresholds of its OLDEST pending tile's stage; every tile of the
+// stages before it holds a smaller ticket, i.e. sits in a block that is running and, by induction over the stages
+// (stage 0 needs no threshold), gets appended.  Spins are bounded all the same: a block that gives up sets the abort
+// word and flags every query, which sends them to the exact fix-up (k_scan_small<FIX>) -- slow, never wrong.
+// Visibility across CUs / XCDs (cdna_hip_programming.md Guideline 16): every shared word is an agent-scope atomic;
+// candidate entries are write-through (sc1) stores, drained by every storing wave before the block's counter add;
+// the selecting block takes one agent-scope acquire before it loads them (with sc1 loads).
+constexpr int CZ_FS_SPINS = 1 << 18;       // polls (~0.5 us apart) before a block gives up: ~0.1 s
+// dynamic LDS of k_sweep_cascade in floats: queries | 4 | ring | 256 hist + 8 words + 2 ring arrays + 4 thresholds
+__host__ __device__ constexpr int cz_fs_lds_floats(int nq_t, int qlen) {
+    return nq_t * qlen + 4 + CZ_FS_RING * nq_t * CZ_T + 256 + 8 + 2 * CZ_FS_RING + 4;
+}
+struct FsSched {
+    int nstage;
+    int first[CZ_FS_MAXST + 1];   // first ticket of stage s; first[nstage] = number of tickets
+    int stride[CZ_FS_MAXST];      // tile stride of stage s
+    int gm1[CZ_FS_MAXST];         // stage s > 0 reads the tiles of its stride that stage s - 1 did not: u + u / gm1 + 1
+};
+#define CZ_AT_LD(P_) __hip_atomic_load((P_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CZ_AT_ST(P_, V_) __hip_atomic_store((P_), (V_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+template <int NQ, int TT, bool I8>
+__global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ rows, const float* __restrict__ x8s,
+                                                       const float* __restrict__ qpad, float* cand_s, uint32_t* cand_i,
+                                                       int* cand_n, float* thr_out, int* flags, int64_t ntotal, int dpad,
+                                                       int nq, FsSched sc, int* fs, const uint32_t* __restrict__ mask,
+                                                       const float* __restrict__ xn2, const float* __restrict__ qnorm2,
+                                                       const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
+                                                       int measured) {
+    // queries (layout of the stage kernels) | [4] offsets | ring | select scratch and block-wide words (all of it in the
+    // dynamic region: statics in front of it would shift its 16-byte alignment)
+    extern __shared__ __attribute__((aligned(16))) float qs[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
+    const int chunks = dpad >> 4;
+    const int steps = I8 ? (TT > 0 ? TT : (chunks + 15) / 16) : (TT > 0 ? TT : (dpad + 127) / 128);
+    const int qlen = I8 ? 256 * steps : dpad;
+    float* qoff = qs + NQ * qlen;
+    float* ring = qoff + 4;          // [CZ_FS_RING][NQ][256] scores of the pending tiles
+    unsigned* hist = reinterpret_cast<unsigned*>(ring + CZ_FS_RING * NQ * CZ_T);   // [256]
+    int* sel = reinterpret_cast<int*>(hist + 256);                                 // [2]
+    int& cnt = sel[2];
+    int& l_tk = sel[3];
+    int& l_ok = sel[4];
+    int& l_last = sel[5];
+    int* ring_stage = sel + 8;                                                      // [CZ_FS_RING]
+    int* ring_u = ring_stage + CZ_FS_RING;                                          // [CZ_FS_RING]
+    float* thr_l = reinterpret_cast<float*>(ring_u + CZ_FS_RING);                   // [4]
+    if constexpr (I8) {
+        for (int i = tid; i < NQ * qlen; i += 256) {
+            const int j = i / qlen, pos = i - j * qlen;
+            const int t = pos >> 8, r = (pos >> 6) & 3, sb = (pos >> 2) & 15, e = pos & 3;
+            const int col = 256 * t + 16 * sb + 4 * r + e;
+            qs[i] = (j < nq && col < dpad) ? qpad[(size_t)j * dpad + col] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq ? qpad[i] : 0.f;
+    }
+    __syncthreads();
+    if (I8 && wave == 0) {   // 128 * sum of the query's elements (the offset of the unsigned bytes)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            float a = 0.f;
+            for (int i = lane; i < qlen; i += 64) a += qs[j * qlen + i];
+            a = wave_allsum(a);
+            if (lane == 0) qoff[j] = 128.f * a;
+        }
+    }
+    __syncthreads();
+    const float my_off = (I8 && sub < NQ) ? qoff[sub < NQ ? sub : 0] : 0.f;
+    const int total = sc.first[sc.nstage];
+    int head = 0, npend = 0, known = 0, cur = 0;
+    bool aborted = false;
+
+    // tests the pending tiles, oldest first, against their stage's thresholds; force: wait for them
+    auto drain = [&](bool force) {
+        int spins = 0;
+        while (npend > 0) {
+            const int slot = (head + CZ_FS_RING - npend) % CZ_FS_RING;
+            const int s = ring_stage[slot];
+            if (s > known) {
+                if (tid == 0) {
+                    int ok = CZ_AT_LD(&fs[1]) == 0 ? 1 : -1;
+                    for (int q = 0; q < nq && ok > 0; ++q) {
+                        const int key = CZ_AT_LD(&fs[CZ_FS_KEY + 4 * s + q]);
+                        if (key == CZ_FS_SENT) ok = 0;
+                        else thr_l[q] = key2f(key);
+                    }
+                    l_ok = ok;
+                }
+                __syncthreads();
+                const int ok = l_ok;
+                __syncthreads();
+                if (ok == 0 && force && ++spins > CZ_FS_SPINS) {   // (never seen: see the kernel's header)
+                    if (tid == 0) {
+                        CZ_AT_ST(&fs[1], 1);
+                        for (int q = 0; q < nq; ++q) CZ_AT_ST(&flags[q], 1);
+                    }
+                    aborted = true;
+                }
+                if (ok < 0 || aborted) {
+                    aborted = true;
+                    npend = 0;
+                    return;
+                }
+                if (ok == 0) {
+                    if (!force) return;
+                    __builtin_amdgcn_s_sleep(16);
+                    continue;
+                }
+                known = s;
+            }
+            const int u = ring_u[slot];
+            const int64_t tile = (int64_t)(s == 0 ? u : u + u / sc.gm1[s] + 1) * sc.stride[s];
+            const int64_t row = tile * CZ_T + tid;
+            const bool row_ok = row < ntotal && CZ_ALLOWED(mask, row);
+            const float* rs = ring + (size_t)slot * NQ * CZ_T;
+            int stored = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q >= nq) break;
+                const float v = rs[q * CZ_T + tid];
+                if (s == 0) {   // stage 0 keeps every score, at fixed slots (cand_n starts at their number)
+                    const size_t o = (size_t)q * CZ_CAP + (size_t)u * CZ_T + tid;
+                    CZ_AT_ST(&cand_s[o], row_ok ? v : -INFINITY);
+                    CZ_AT_ST(&cand_i[o], row_ok ? (uint32_t)row : kInvalidRow);
+                    stored = 1;
+                } else if (row_ok && v >= thr_l[q]) {
+                    const int at = atomicAdd(&cand_n[(size_t)q * CZ_NS], 1);
+                    if (at < CZ_CAP) {
+                        CZ_AT_ST(&cand_s[(size_t)q * CZ_CAP + at], v);
+                        CZ_AT_ST(&cand_i[(size_t)q * CZ_CAP + at], (uint32_t)row);
+                    }
+                    stored = 1;
+                }
+            }
+            --npend;
+            if (s + 1 >= sc.nstage) {   // the last stage: nothing in this launch waits for it
+                __syncthreads();        // (the ring slot may be refilled)
+                continue;
+            }
+            if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its entries ...
+            __syncthreads();                                               // ... before the block counts its tile
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(&fs[CZ_FS_DONE + s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old + 1 == sc.first[s + 1] - sc.first[s];
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                l_last = last;
+            }
+            __syncthreads();
+            if (!l_last) continue;
+            // ---- select(s): k-th best coarse score of everything seen, thresholds of stage s + 1, buffer cut to them
+            for (int q = 0; q < nq; ++q) {
+                const int n_raw = CZ_AT_LD(&cand_n[(size_t)q * CZ_NS]);
+                const int n = min(n_raw, CZ_CAP);
+                constexpr int E = CZ_CAP / 256;
+                unsigned key[E], id[E], live = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid + 256 * e;
+                    key[e] = 0;
+                    id[e] = kInvalidRow;
+                    if (i < n) {
+                        const float v = CZ_AT_LD(&cand_s[(size_t)q * CZ_CAP + i]);
+                        key[e] = (unsigned)f2key(v) ^ 0x80000000u;   // unsigned order = float order
+                        id[e] = CZ_AT_LD(&cand_i[(size_t)q * CZ_CAP + i]);
+                        live |= 1u << e;
+                    }
+                }
+                if (tid == 0) cnt = 0;
+                __syncthreads();   // (every load above has landed before any entry is rewritten: the keys are used below)
+                const float Tc = n >= k ? cz_kth_largest_regs<E>(key, live, k, hist, sel, tid) : -INFINITY;
+                const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(maxn2_bits[0]), l2,
+                                         measured ? __int_as_float(maxn2_bits[measured]) : -1.f, 0.f);
+                float thr_new = Tc - 2.f * eps;  // -inf stays -inf
+                if (!(thr_new == thr_new)) thr_new = -INFINITY;   // NaN scores: keep everything (the query ends up flagged)
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float v = key2f((int)(key[e] ^ 0x80000000u));
+                    if (((live >> e) & 1u) && v >= thr_new && id[e] != kInvalidRow) {
+                        const int pos = atomicAdd(&cnt, 1);
+                        CZ_AT_ST(&cand_s[(size_t)q * CZ_CAP + pos], v);
+                        CZ_AT_ST(&cand_i[(size_t)q * CZ_CAP + pos], id[e]);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    CZ_AT_ST(&cand_n[(size_t)q * CZ_NS], cnt);
+                    thr_out[q] = thr_new;
+                    if (n_raw > CZ_CAP) CZ_AT_ST(&flags[q], 1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the count is in place before anybody may append
+                    CZ_AT_ST(&fs[CZ_FS_KEY + 4 * (s + 1) + q], f2key(thr_new));
+                }
+                __syncthreads();
+            }
+        }
+    };
+
+    int tk_next = 0;
+    if (tid == 0) tk_next = __hip_atomic_fetch_add(&fs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (tid == 0) l_tk = tk_next;
+        __syncthreads();
+        const int t = l_tk;
+        if (t >= total || aborted) break;
+        // (the next ticket travels while this tile is scored)
+        if (tid == 0) tk_next = __hip_atomic_fetch_add(&fs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (t >= sc.first[cur + 1]) ++cur;
+        const int u = t - sc.first[cur];
+        const int64_t tile = (int64_t)(cur == 0 ? u : u + u / sc.gm1[cur] + 1) * sc.stride[cur];
+        const int64_t row_base = tile * CZ_T + wave * 64;
+        float* rs = ring + (size_t)head * NQ * CZ_T;
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
+            if constexpr (NQ > 1) asm volatile("" ::: "memory");
+            const int64_t rowA = row_base + it * 4 + rg, rowB = rowA + 4;
+            const int64_t ra_ = rowA < ntotal ? rowA : ntotal - 1, rb_ = rowB < ntotal ? rowB : ntotal - 1;
+            float ma, mb;
+            if constexpr (I8)
+                cz_sweep_pair_i8<NQ, TT>(static_cast<const unsigned char*>(rows), x8s, qs, qlen, my_off, ra_, rb_, dpad, chunks,
+                                         steps, sub, xn2, ma, mb);
+            else
+                cz_sweep_pair_bf16<NQ, TT>(static_cast<const unsigned short*>(rows), qs, ra_, rb_, dpad, steps, sub, xn2, ma, mb);
+            if (sub < NQ) {
+                rs[sub * CZ_T + wave * 64 + it * 4 + rg] = ma;
+                rs[sub * CZ_T + wave * 64 + it * 4 + rg + 4] = mb;
+            }
+        }
+        if (tid == 0) {
+            ring_stage[head] = cur;
+            ring_u[head] = u;
+        }
+        head = (head + 1) % CZ_FS_RING;
+        ++npend;
+        __syncthreads();
+        drain(npend == CZ_FS_RING);
+    }
+    drain(true);
 }
 
 // Work list of the band rescoring: the (query, part) items that exist, in query order -- one block, an exclusive

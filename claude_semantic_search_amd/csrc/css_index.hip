@@ -1513,7 +1513,7 @@ struct KnnEnv {
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
-    int sweep_fused = 0;    // CSS_KNN_SWEEP_FUSED=1: k_sweep_cascade (one launch) instead of one launch per stage and select of that cascade
+    int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0: one launch per stage and select of that cascade (A/B runs) instead of k_sweep_cascade
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
@@ -1956,11 +1956,11 @@ int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSch
     auto kern = k_sweep_cascade<NQ, TT, I8>;
     int rc;
     if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
-    // as many blocks as the chip holds at once (a block leaves only when the tickets run out: more would start at the
-    // very end, load the queries and find nothing to do); nothing depends on the blocks being co-resident
+    // as many blocks as the chip holds at once (a wave leaves only when the tickets run out: more blocks would start at
+    // the very end, load the queries and find nothing to do); nothing depends on the blocks being co-resident
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * std::min(per_cu, 8), sc.first[sc.nstage]);
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * std::min(per_cu, 8), (sc.first[sc.nstage] + 3) / 4);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, I8 ? (const void*)ix->x8 : (const void*)ix->xh,
                        I8 ? (const float*)ix->x8s : (const float*)nullptr, qpad, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
                        flags, ix->ntotal, ix->dpad, nq, sc, ix->fs_state, ix->cur_mask,
@@ -2081,8 +2081,8 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         }
     }
     const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
-    // 1..4 queries: the stages and the selects between them as ONE launch (k_sweep_cascade), tiles as tickets in stage order
-    bool fused = sweep && env.sweep_fused && (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 30;
+    // 1..4 queries: the stages and the selects between them as ONE launch (k_sweep_cascade), quarter tiles as tickets in stage order
+    bool fused = sweep && env.sweep_fused && (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 28;
     FsSched fsched{};
     if (fused) {
         fsched.nstage = (int)sched.size();
@@ -2095,7 +2095,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             fsched.first[si] = (int)first;
             fsched.stride[si] = (int)sched[si].stride;
             fsched.gm1[si] = std::max(1, gr - 1);
-            first += count;
+            first += 4 * count;   // tickets are quarter tiles
         }
         fsched.first[sched.size()] = (int)first;
         if (fused && (rc = grow(&ix->fs_state, &ix->fs_state_cap, (size_t)CZ_FS_WORDS)) != CSS_OK) return rc;
@@ -2118,7 +2118,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             CSS_LAUNCH_CHECK();
         }
         const int npace = use_pace ? kPaceGroups * kPaceStages : 0;
-        const int ninit = std::max(std::max(std::max(nq_pad, npace), f2), fused ? CZ_FS_WORDS : 0);
+        const int ninit = std::max(std::max(std::max(nq_pad, npace), f2), fused ? CZ_FS_KEYWORDS : 0);
         hipLaunchKernelGGL(k_coarse_init, dim3((ninit + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T), use_pace ? ix->cpace : (int*)nullptr, npace,
                            pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2,

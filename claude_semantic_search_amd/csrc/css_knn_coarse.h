@@ -144,11 +144,15 @@ constexpr int CZ_PARTS = 16;
 constexpr int CZ_NS = 1;
 // k_sweep_cascade (the 1..4-query cascade in one launch, below): its limits and its state words
 constexpr int CZ_FS_MAXST = 16;            // stages (growth 4: 4^15 tiles)
-constexpr int CZ_FS_RING = 4;              // pending tiles per block
+constexpr int CZ_FS_RING = 16;             // pending quarter tiles per wave
 constexpr int CZ_FS_SENT = 0x7FFFFFFF;     // key word "not published yet" (a NaN's key: a published threshold never is one)
-// state words (k_coarse_init): [0] next ticket | [1] abort | [2 + s] tiles of stage s appended | key of the threshold
-// that stage s applies to query q at [CZ_FS_KEY + 4 s + q]
-constexpr int CZ_FS_DONE = 2, CZ_FS_KEY = CZ_FS_DONE + CZ_FS_MAXST, CZ_FS_WORDS = CZ_FS_KEY + 4 * CZ_FS_MAXST;
+// state words (k_coarse_init).  Agent-scope atomics AND sc1 loads of one 128-byte line complete at only ~30 per microsecond
+// chip-wide (they are served behind the L2s), so every hot word has a line -- and a 4-KiB stride: a channel -- of its own:
+// [0] next ticket | [LINE] abort | [LINE (2 + s)] quarters of stage s appended | from CZ_FS_KEY: CZ_FS_COPIES copies (one per
+// blockIdx % CZ_FS_COPIES, 256 bytes each) of the key words, [4 s + q] = threshold that stage s applies to query q
+constexpr int CZ_FS_LINE = 1024, CZ_FS_COPIES = 64;
+constexpr int CZ_FS_ABORT = CZ_FS_LINE, CZ_FS_DONE = 2 * CZ_FS_LINE, CZ_FS_KEY = (2 + CZ_FS_MAXST) * CZ_FS_LINE;
+constexpr int CZ_FS_KEYWORDS = 4 * CZ_FS_MAXST * CZ_FS_COPIES, CZ_FS_WORDS = CZ_FS_KEY + CZ_FS_KEYWORDS;
 
 // thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
 // the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
@@ -158,7 +162,10 @@ __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, i
                               int* __restrict__ nflagB, int f2max, int* __restrict__ fs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // k_sweep_cascade: counters zero, stage 0 open (threshold -inf), every later stage unpublished
-    if (fs != nullptr && i < CZ_FS_WORDS) fs[i] = i < CZ_FS_KEY ? 0 : (i < CZ_FS_KEY + 4 ? f2key(-INFINITY) : CZ_FS_SENT);
+    if (fs != nullptr && i < CZ_FS_KEYWORDS) {
+        fs[CZ_FS_KEY + i] = (i & (4 * CZ_FS_MAXST - 1)) < 4 ? f2key(-INFINITY) : CZ_FS_SENT;
+        if (i < 2 + CZ_FS_MAXST) fs[i * CZ_FS_LINE] = 0;
+    }
     if (i == 0) {
         *nflag = 0;
         if (nflagB) *nflagB = 0;
@@ -1380,35 +1387,42 @@ constexpr int CZ_FLAGGED_RESCORE = 512;
 // query, 0.35 ms of the 2.8 ms single-query search (7 selects in a row).  Block of 256 threads; hist: 256 words of LDS.
 // (one digit of that selection: hist holds the counts of the 256 digit values among the keys still in play; wave 0 finds the
 // bin of the kk-th largest and the number of keys in the bins above it -- sel[0], sel[1]; ends with a block barrier)
-__device__ __forceinline__ void cz_radix_pick(const unsigned* hist, int kk, int* sel, int tid) {
-    if (tid < 64) {   // lane l owns bins 255 - 4 l .. 252 - 4 l; cum = keys in its bins and all higher ones
-        const int b0 = 255 - 4 * tid;
-        const unsigned c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
-        const unsigned tot = (c0 + c1) + (c2 + c3);
-        unsigned cum = tot;
+__device__ __forceinline__ unsigned long long cz_radix_lane(const unsigned* hist, int kk, int lane, int& bsel, int& above) {
+    // lane l owns bins 255 - 4 l .. 252 - 4 l; cum = keys in its bins and all higher ones.  Returns the lanes whose cum
+    // reaches kk: the lowest of them holds the kk-th largest's bin (bsel) and the number of keys in the bins above it
+    const int b0 = 255 - 4 * lane;
+    const unsigned c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+    const unsigned tot = (c0 + c1) + (c2 + c3);
+    unsigned cum = tot;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = (unsigned)__shfl_up((int)cum, o);
-            if (tid >= o) cum += v;
-        }
-        const unsigned long long hit = __ballot(cum >= (unsigned)kk);   // (never empty: the candidates of this pass number >= kk)
-        if (tid == __ffsll((long long)hit) - 1) {
-            unsigned a = cum - tot;
-            int bsel = b0;
-            if (a + c0 < (unsigned)kk) {
-                a += c0;
-                bsel = b0 - 1;
-                if (a + c1 < (unsigned)kk) {
-                    a += c1;
-                    bsel = b0 - 2;
-                    if (a + c2 < (unsigned)kk) {
-                        a += c2;
-                        bsel = b0 - 3;
-                    }
-                }
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)cum, o);
+        if (lane >= o) cum += v;
+    }
+    unsigned a = cum - tot;
+    bsel = b0;
+    if (a + c0 < (unsigned)kk) {
+        a += c0;
+        bsel = b0 - 1;
+        if (a + c1 < (unsigned)kk) {
+            a += c1;
+            bsel = b0 - 2;
+            if (a + c2 < (unsigned)kk) {
+                a += c2;
+                bsel = b0 - 3;
             }
+        }
+    }
+    above = (int)a;
+    return __ballot(cum >= (unsigned)kk);   // (never empty: the candidates of this pass number >= kk)
+}
+__device__ __forceinline__ void cz_radix_pick(const unsigned* hist, int kk, int* sel, int tid) {
+    if (tid < 64) {
+        int bsel, above;
+        const unsigned long long hit = cz_radix_lane(hist, kk, tid, bsel, above);
+        if (tid == __ffsll((long long)hit) - 1) {
             sel[0] = bsel;
-            sel[1] = (int)a;
+            sel[1] = above;
         }
     }
     __syncthreads();
@@ -1433,28 +1447,6 @@ __device__ __forceinline__ float cz_kth_largest(const float* s, int n, int k, un
     }
     return key2f((int)(prefix ^ 0x80000000u));
 }
-// The same over keys held in registers: entry e of thread tid is candidate tid + 256 e, `live` bit e says it exists.
-template <int E>
-__device__ __forceinline__ float cz_kth_largest_regs(const unsigned (&key)[E], unsigned live, int k, unsigned* hist, int* sel, int tid) {
-    unsigned prefix = 0, mask = 0;
-    int kk = k;
-#pragma unroll 1
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (((live >> e) & 1u) && (key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> shift) & 255u], 1u);
-        __syncthreads();
-        cz_radix_pick(hist, kk, sel, tid);
-        prefix |= (unsigned)sel[0] << shift;
-        mask |= 0xFFu << shift;
-        kk -= sel[1];
-        __syncthreads();
-    }
-    return key2f((int)(prefix ^ 0x80000000u));
-}
-
 template <bool FINAL>
 __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_s, uint32_t* __restrict__ cand_i,
                                                        int* __restrict__ cand_n, float* __restrict__ thr,
@@ -1619,32 +1611,75 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
 
 // ------------------------------------------------------------------ the 1..4-query cascade in ONE launch
 // k_sweep_cascade runs every stage of the sweep cascade (the schedule of launch_scan_coarse) and the selects between
-// them in one persistent launch: 8 sweeps + 7 one-block selects at 10 M rows cost 0.25 ms of launch gaps, ramps and
-// tails on top of the bytes.  Row tiles are TICKETS in stage order (stage 0 first, the stride-1 stage last), drawn
-// from one counter by whichever block is free, so the stages pack without tails.  A block scores its tile into an LDS
-// ring of CZ_FS_RING pending tiles and tests a pending tile against its stage's thresholds once those are
-// published; the block whose tile is the last of stage s to be appended (counter of stage s) runs select(s) -- the
-// arithmetic of k_coarse_select<false> -- and publishes the thresholds of stage s + 1 as key words.
-// No wait can deadlock: a block waits only for the thresholds of its OLDEST pending tile's stage; every tile of the
-// stages before it holds a smaller ticket, i.e. sits in a block that is running and, by induction over the stages
-// (stage 0 needs no threshold), gets appended.  Spins are bounded all the same: a block that gives up sets the abort
-// word and flags every query, which sends them to the exact fix-up (k_scan_small<FIX>) -- slow, never wrong.
+// them in one persistent launch: 8 sweeps + 7 one-block selects at 10 M rows cost ~0.25 ms of launch gaps, ramps and
+// tails on top of the bytes.  The unit of work is a QUARTER tile (64 rows: what one wave covers of a tile in the stage
+// kernels); quarters are TICKETS in stage order (stage 0 first, the stride-1 stage last).
+// Tickets are dealt in two levels, because agent-scope atomics on ONE address complete at only ~30 per microsecond on this
+// chip (measured: a counter add per tile made the launch atomic-bound, 1.5-3.6 ms): a block takes a CHUNK of
+// consecutive tickets from the global counter (4 in the short early stages, up to 64 in the long ones, shrinking
+// again over the last stretch), its four waves draw single tickets from the chunk with one 64-bit LDS add.
+// Every WAVE is an agent of its own -- no block barrier after the prologue: it scores its quarter into its LDS ring of
+// CZ_FS_RING pending quarters and tests a pending quarter against its stage's thresholds once those are published.  A
+// wave counts the quarters it has appended per stage and adds them to the stage's counter when it moves on to another
+// stage; the wave whose add completes stage s runs select(s) -- the arithmetic of k_coarse_select<false>, by one
+// wave over the buffer in L2 -- and publishes the thresholds of stage s + 1 as key words.
+// No wait can deadlock, whatever part of the grid is resident: chunks are claimed in ticket order and a block's waves
+// draw a chunk in order, so the smallest ticket not yet appended is always either being scored or the OLDEST pending
+// quarter of its wave, and the thresholds it waits for depend on smaller tickets only (stage 0 needs none).  Spins are
+// bounded all the same: a wave that gives up sets the abort word and flags every query, which sends them to the
+// exact fix-up (k_scan_small<FIX>) -- slow, never wrong.
 // Visibility across CUs / XCDs (cdna_hip_programming.md Guideline 16): every shared word is an agent-scope atomic;
-// candidate entries are write-through (sc1) stores, drained by every storing wave before the block's counter add;
-// the selecting block takes one agent-scope acquire before it loads them (with sc1 loads).
-constexpr int CZ_FS_SPINS = 1 << 18;       // polls (~0.5 us apart) before a block gives up: ~0.1 s
-// dynamic LDS of k_sweep_cascade in floats: queries | 4 | ring | 256 hist + 8 words + 2 ring arrays + 4 thresholds
+// candidate entries are write-through (sc1) stores, drained by the storing wave before its counter add; the selecting
+// wave takes one agent-scope acquire before it loads them (with sc1 loads).
+constexpr int CZ_FS_SPINS = 1 << 18;       // polls (~0.5 us apart) before a wave gives up: ~0.1 s
+// dynamic LDS of k_sweep_cascade in floats: queries | 4 offsets | 4 (the block's chunk word) | 4 waves x (ring | 256 bins | 2 ring arrays)
 __host__ __device__ constexpr int cz_fs_lds_floats(int nq_t, int qlen) {
-    return nq_t * qlen + 4 + CZ_FS_RING * nq_t * CZ_T + 256 + 8 + 2 * CZ_FS_RING + 4;
+    return nq_t * qlen + 4 + 4 + 4 * (CZ_FS_RING * nq_t * 64 + 256 + 2 * CZ_FS_RING);
 }
 struct FsSched {
     int nstage;
-    int first[CZ_FS_MAXST + 1];   // first ticket of stage s; first[nstage] = number of tickets
+    int first[CZ_FS_MAXST + 1];   // first ticket (quarter tile) of stage s; first[nstage] = number of tickets
     int stride[CZ_FS_MAXST];      // tile stride of stage s
     int gm1[CZ_FS_MAXST];         // stage s > 0 reads the tiles of its stride that stage s - 1 did not: u + u / gm1 + 1
 };
 #define CZ_AT_LD(P_) __hip_atomic_load((P_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define CZ_AT_ST(P_, V_) __hip_atomic_store((P_), (V_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// LDS traffic between the lanes of ONE wave: its DS operations execute in order, what has to be stopped is the compiler
+#define CZ_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// k-th largest of the n floats at s (global memory, other CUs' write-through stores: sc1 loads) by ONE wave: the
+// radix selection of cz_kth_largest with the wave's own 256 bins
+__device__ __forceinline__ float cz_kth_largest_wave(const float* s, int n, int k, unsigned* hist, int lane) {
+    unsigned prefix = 0, mask = 0;
+    int kk = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[lane] = hist[lane + 64] = hist[lane + 128] = hist[lane + 192] = 0;
+        CZ_WAVE_LDS_SYNC();
+        for (int c = 0; c < n; c += 64 * 8) {   // 8 loads in flight per lane (each is an L2 round trip)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = c + 64 * j + lane;
+                v[j] = i < n ? CZ_AT_LD(&s[i]) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned u = (unsigned)f2key(v[j]) ^ 0x80000000u;   // unsigned order = float order
+                if (c + 64 * j + lane < n && (u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
+        }
+        CZ_WAVE_LDS_SYNC();
+        int bsel, above;
+        const unsigned long long hit = cz_radix_lane(hist, kk, lane, bsel, above);
+        const int src = __ffsll((long long)hit) - 1;
+        prefix |= (unsigned)__shfl(bsel, src) << shift;
+        mask |= 0xFFu << shift;
+        kk -= __shfl(above, src);
+        CZ_WAVE_LDS_SYNC();
+    }
+    return key2f((int)(prefix ^ 0x80000000u));
+}
 
 template <int NQ, int TT, bool I8>
 __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ rows, const float* __restrict__ x8s,
@@ -1654,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
                                                        const float* __restrict__ xn2, const float* __restrict__ qnorm2,
                                                        const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
                                                        int measured) {
-    // queries (layout of the stage kernels) | [4] offsets | ring | select scratch and block-wide words (all of it in the
+    // queries (layout of the stage kernels) | [4] offsets | per wave: ring, bins, ring bookkeeping (all of it in the
     // dynamic region: statics in front of it would shift its 16-byte alignment)
     extern __shared__ __attribute__((aligned(16))) float qs[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, rg = lane >> 4;
@@ -1662,16 +1697,13 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
     const int steps = I8 ? (TT > 0 ? TT : (chunks + 15) / 16) : (TT > 0 ? TT : (dpad + 127) / 128);
     const int qlen = I8 ? 256 * steps : dpad;
     float* qoff = qs + NQ * qlen;
-    float* ring = qoff + 4;          // [CZ_FS_RING][NQ][256] scores of the pending tiles
-    unsigned* hist = reinterpret_cast<unsigned*>(ring + CZ_FS_RING * NQ * CZ_T);   // [256]
-    int* sel = reinterpret_cast<int*>(hist + 256);                                 // [2]
-    int& cnt = sel[2];
-    int& l_tk = sel[3];
-    int& l_ok = sel[4];
-    int& l_last = sel[5];
-    int* ring_stage = sel + 8;                                                      // [CZ_FS_RING]
-    int* ring_u = ring_stage + CZ_FS_RING;                                          // [CZ_FS_RING]
-    float* thr_l = reinterpret_cast<float*>(ring_u + CZ_FS_RING);                   // [4]
+    // the block's chunk of tickets: first ticket << 32 | size << 16 | tickets drawn (first = -1: none yet, = total: the end)
+    unsigned long long* chunk = reinterpret_cast<unsigned long long*>(qoff + 4);
+    constexpr int kWaveWords = CZ_FS_RING * NQ * 64 + 256 + 2 * CZ_FS_RING;
+    float* ring = qoff + 8 + wave * kWaveWords;                          // [CZ_FS_RING][NQ][64] scores of the pending quarters
+    unsigned* hist = reinterpret_cast<unsigned*>(ring + CZ_FS_RING * NQ * 64);   // [256]
+    int* ring_stage = reinterpret_cast<int*>(hist + 256);                // [CZ_FS_RING] stage of a pending quarter ...
+    int* ring_rel = ring_stage + CZ_FS_RING;                             // ... and its ticket relative to the stage's first
     if constexpr (I8) {
         for (int i = tid; i < NQ * qlen; i += 256) {
             const int j = i / qlen, pos = i - j * qlen;
@@ -1682,6 +1714,7 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
     } else {
         for (int i = tid; i < NQ * dpad; i += 256) qs[i] = (i / dpad) < nq ? qpad[i] : 0.f;
     }
+    if (tid == 0) *chunk = 0xFFFFFFFFull << 32;
     __syncthreads();
     if (I8 && wave == 0) {   // 128 * sum of the query's elements (the offset of the unsigned bytes)
 #pragma unroll
@@ -1692,39 +1725,125 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
             if (lane == 0) qoff[j] = 128.f * a;
         }
     }
-    __syncthreads();
+    __syncthreads();   // the last block barrier: from here on every wave runs on its own
     const float my_off = (I8 && sub < NQ) ? qoff[sub < NQ ? sub : 0] : 0.f;
     const int total = sc.first[sc.nstage];
+    const int long_from = sc.first[sc.nstage > 2 ? sc.nstage - 2 : 0];   // the two long stages start here
+    const int* keys = fs + CZ_FS_KEY + ((int)blockIdx.x % CZ_FS_COPIES) * 4 * CZ_FS_MAXST;   // this block's copy of the key words
     int head = 0, npend = 0, known = 0, cur = 0;
-    bool aborted = false;
+    int acc_stage = 0, acc_n = 0;   // quarters of stage acc_stage this wave has appended and not yet added to the stage's counter
+    bool acc_stored = false, aborted = false;
+    float thr[NQ];   // thresholds of stage `known`
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) thr[q] = -INFINITY;
 
-    // tests the pending tiles, oldest first, against their stage's thresholds; force: wait for them
+    // first row of ticket `rel` of stage s (a quarter of the tile the stage kernels would give their block)
+    auto quarter_rows = [&](int s, int rel) -> int64_t {
+        const int u = rel >> 2;
+        const int64_t tile = (int64_t)(s == 0 ? u : u + u / sc.gm1[s] + 1) * sc.stride[s];
+        return tile * CZ_T + (rel & 3) * 64;
+    };
+
+    // select(s), by this wave: k-th best coarse score of everything seen, thresholds of stage s + 1, buffer cut to them
+    auto select_stage = [&](int s) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int thr_key[4] = {0, 0, 0, 0};
+        for (int q = 0; q < nq; ++q) {
+            float* cs = cand_s + (size_t)q * CZ_CAP;
+            uint32_t* ci = cand_i + (size_t)q * CZ_CAP;
+            const int n_raw = CZ_AT_LD(&cand_n[(size_t)q * CZ_NS]);
+            const int n = min(n_raw, CZ_CAP);
+            const float Tc = n >= k ? cz_kth_largest_wave(cs, n, k, hist, lane) : -INFINITY;
+            const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(maxn2_bits[0]), l2,
+                                     measured ? __int_as_float(maxn2_bits[measured]) : -1.f, 0.f);
+            float thr_new = Tc - 2.f * eps;  // -inf stays -inf
+            if (!(thr_new == thr_new)) thr_new = -INFINITY;   // NaN scores: keep everything (the query ends up flagged)
+            // the band, compacted in place 64 entries at a time (a chunk is in registers before anything is written,
+            // and what is written lies in front of the chunks still to be read)
+            int kept = 0;
+            for (int c = 0; c < n; c += 64 * 4) {   // (4 chunks loaded before the first is written)
+                float v[4];
+                uint32_t id[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = c + 64 * j + lane;
+                    v[j] = -INFINITY;
+                    id[j] = kInvalidRow;
+                    if (i < n) {
+                        v[j] = CZ_AT_LD(&cs[i]);
+                        id[j] = CZ_AT_LD(&ci[i]);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool keep = c + 64 * j + lane < n && v[j] >= thr_new && id[j] != kInvalidRow;
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) {
+                        const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+                        CZ_AT_ST(&cs[pos], v[j]);
+                        CZ_AT_ST(&ci[pos], id[j]);
+                    }
+                    kept += __popcll(m);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                CZ_AT_ST(&cand_n[(size_t)q * CZ_NS], kept);
+                thr_out[q] = thr_new;
+                if (n_raw > CZ_CAP) CZ_AT_ST(&flags[q], 1);
+            }
+            thr_key[q] = f2key(thr_new);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counts are in place before anybody may append
+        static_assert(CZ_FS_COPIES == 64, "one copy of the key words per lane");
+        for (int q = 0; q < nq; ++q) CZ_AT_ST(&fs[CZ_FS_KEY + lane * 4 * CZ_FS_MAXST + 4 * (s + 1) + q], thr_key[q]);
+    };
+
+    // adds the quarters this wave has appended to their stage's counter; the add that completes the stage runs its select
+    auto publish = [&]() {
+        if (acc_n == 0) return;
+        if (acc_stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's entries are out before it counts them
+        int last = 0;
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(&fs[CZ_FS_DONE + acc_stage * CZ_FS_LINE], acc_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old + acc_n == sc.first[acc_stage + 1] - sc.first[acc_stage];
+        }
+        const int s = acc_stage;
+        acc_n = 0;
+        acc_stored = false;
+        if (__builtin_amdgcn_readfirstlane(last)) select_stage(s);
+    };
+
+    // tests the pending quarters, oldest first, against their stage's thresholds; force: wait for them
     auto drain = [&](bool force) {
         int spins = 0;
         while (npend > 0) {
             const int slot = (head + CZ_FS_RING - npend) % CZ_FS_RING;
-            const int s = ring_stage[slot];
-            if (s > known) {
-                if (tid == 0) {
-                    int ok = CZ_AT_LD(&fs[1]) == 0 ? 1 : -1;
-                    for (int q = 0; q < nq && ok > 0; ++q) {
-                        const int key = CZ_AT_LD(&fs[CZ_FS_KEY + 4 * s + q]);
-                        if (key == CZ_FS_SENT) ok = 0;
-                        else thr_l[q] = key2f(key);
+            const int s = __builtin_amdgcn_readfirstlane(ring_stage[slot]);
+            if (s != acc_stage) publish();   // (this wave has moved on: what it appended of the earlier stage counts now)
+            if (s > known) {   // (every lane polls the same words -- this block's copy: one request per load)
+                int ok = (force && (spins & 63) == 63 && CZ_AT_LD(&fs[CZ_FS_ABORT]) != 0) ? -1 : 1;
+                float tq[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    tq[q] = -INFINITY;
+                    if (q < nq) {
+                        const int key = CZ_AT_LD(&keys[4 * s + q]);
+                        if (key == CZ_FS_SENT) ok = ok > 0 ? 0 : ok;
+                        tq[q] = key2f(key);
                     }
-                    l_ok = ok;
                 }
-                __syncthreads();
-                const int ok = l_ok;
-                __syncthreads();
+                ok = __builtin_amdgcn_readfirstlane(ok);
                 if (ok == 0 && force && ++spins > CZ_FS_SPINS) {   // (never seen: see the kernel's header)
-                    if (tid == 0) {
-                        CZ_AT_ST(&fs[1], 1);
+                    if (lane == 0) {
+                        CZ_AT_ST(&fs[CZ_FS_ABORT], 1);
                         for (int q = 0; q < nq; ++q) CZ_AT_ST(&flags[q], 1);
                     }
-                    aborted = true;
+                    ok = -1;
                 }
-                if (ok < 0 || aborted) {
+                if (ok < 0) {
                     aborted = true;
                     npend = 0;
                     return;
@@ -1735,112 +1854,84 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
                     continue;
                 }
                 known = s;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) thr[q] = tq[q];
             }
-            const int u = ring_u[slot];
-            const int64_t tile = (int64_t)(s == 0 ? u : u + u / sc.gm1[s] + 1) * sc.stride[s];
-            const int64_t row = tile * CZ_T + tid;
+            const int rel = __builtin_amdgcn_readfirstlane(ring_rel[slot]);
+            const int64_t row = quarter_rows(s, rel) + lane;
             const bool row_ok = row < ntotal && CZ_ALLOWED(mask, row);
-            const float* rs = ring + (size_t)slot * NQ * CZ_T;
-            int stored = 0;
+            const float* rs = ring + slot * NQ * 64;
+            bool stored = false;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (q >= nq) break;
-                const float v = rs[q * CZ_T + tid];
+                const float v = rs[q * 64 + lane];
                 if (s == 0) {   // stage 0 keeps every score, at fixed slots (cand_n starts at their number)
-                    const size_t o = (size_t)q * CZ_CAP + (size_t)u * CZ_T + tid;
+                    const size_t o = (size_t)q * CZ_CAP + (size_t)rel * 64 + lane;
                     CZ_AT_ST(&cand_s[o], row_ok ? v : -INFINITY);
                     CZ_AT_ST(&cand_i[o], row_ok ? (uint32_t)row : kInvalidRow);
-                    stored = 1;
-                } else if (row_ok && v >= thr_l[q]) {
+                    stored = true;
+                } else if (row_ok && v >= thr[q]) {
                     const int at = atomicAdd(&cand_n[(size_t)q * CZ_NS], 1);
                     if (at < CZ_CAP) {
                         CZ_AT_ST(&cand_s[(size_t)q * CZ_CAP + at], v);
                         CZ_AT_ST(&cand_i[(size_t)q * CZ_CAP + at], (uint32_t)row);
                     }
-                    stored = 1;
+                    stored = true;
                 }
             }
             --npend;
-            if (s + 1 >= sc.nstage) {   // the last stage: nothing in this launch waits for it
-                __syncthreads();        // (the ring slot may be refilled)
+            if (s + 1 >= sc.nstage) continue;   // the last stage: nothing in this launch waits for it
+            acc_stage = s;
+            ++acc_n;
+            acc_stored |= __ballot(stored) != 0ull;
+        }
+    };
+
+    // one ticket for this wave, or -1 when they are used up
+    auto draw = [&]() -> int {
+        int spins = 0;
+        for (;;) {
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicAdd(chunk, 1ull);
+            const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)old), first = __builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
+            const int drawn = lo & 0xFFFF, size = (lo >> 16) & 0xFFFF;
+            if (first == total) return -1;
+            if (drawn < size) return first + drawn;
+            if (drawn == size) {   // the draw that found the chunk used up fetches the block's next one
+                // 4 tickets (one per wave) in the short early stages, whose selects wait for the slowest quarter; up to 64
+                // in the long ones, shrinking over the last stretch so that the blocks finish together
+                const int pos = first < 0 ? 0 : first + size;
+                int want = 4;
+                if (pos >= long_from) want = min(64, max(4, ((total - pos) / (2 * (int)gridDim.x)) & ~3));
+                int g = 0;
+                if (lane == 0) g = __hip_atomic_fetch_add(&fs[0], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g = __builtin_amdgcn_readfirstlane(g);
+                const unsigned long long word = g >= total ? (unsigned long long)(unsigned)total << 32
+                                                           : ((unsigned long long)(unsigned)g << 32) | ((unsigned long long)min(want, total - g) << 16);
+                if (lane == 0) __hip_atomic_store(chunk, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                CZ_WAVE_LDS_SYNC();
                 continue;
             }
-            if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its entries ...
-            __syncthreads();                                               // ... before the block counts its tile
-            if (tid == 0) {
-                const int old = __hip_atomic_fetch_add(&fs[CZ_FS_DONE + s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = old + 1 == sc.first[s + 1] - sc.first[s];
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                l_last = last;
-            }
-            __syncthreads();
-            if (!l_last) continue;
-            // ---- select(s): k-th best coarse score of everything seen, thresholds of stage s + 1, buffer cut to them
-            for (int q = 0; q < nq; ++q) {
-                const int n_raw = CZ_AT_LD(&cand_n[(size_t)q * CZ_NS]);
-                const int n = min(n_raw, CZ_CAP);
-                constexpr int E = CZ_CAP / 256;
-                unsigned key[E], id[E], live = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = tid + 256 * e;
-                    key[e] = 0;
-                    id[e] = kInvalidRow;
-                    if (i < n) {
-                        const float v = CZ_AT_LD(&cand_s[(size_t)q * CZ_CAP + i]);
-                        key[e] = (unsigned)f2key(v) ^ 0x80000000u;   // unsigned order = float order
-                        id[e] = CZ_AT_LD(&cand_i[(size_t)q * CZ_CAP + i]);
-                        live |= 1u << e;
-                    }
-                }
-                if (tid == 0) cnt = 0;
-                __syncthreads();   // (every load above has landed before any entry is rewritten: the keys are used below)
-                const float Tc = n >= k ? cz_kth_largest_regs<E>(key, live, k, hist, sel, tid) : -INFINITY;
-                const float eps = cz_eps(eps_rel, qnorm2[q], __int_as_float(maxn2_bits[0]), l2,
-                                         measured ? __int_as_float(maxn2_bits[measured]) : -1.f, 0.f);
-                float thr_new = Tc - 2.f * eps;  // -inf stays -inf
-                if (!(thr_new == thr_new)) thr_new = -INFINITY;   // NaN scores: keep everything (the query ends up flagged)
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float v = key2f((int)(key[e] ^ 0x80000000u));
-                    if (((live >> e) & 1u) && v >= thr_new && id[e] != kInvalidRow) {
-                        const int pos = atomicAdd(&cnt, 1);
-                        CZ_AT_ST(&cand_s[(size_t)q * CZ_CAP + pos], v);
-                        CZ_AT_ST(&cand_i[(size_t)q * CZ_CAP + pos], id[e]);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    CZ_AT_ST(&cand_n[(size_t)q * CZ_NS], cnt);
-                    thr_out[q] = thr_new;
-                    if (n_raw > CZ_CAP) CZ_AT_ST(&flags[q], 1);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the count is in place before anybody may append
-                    CZ_AT_ST(&fs[CZ_FS_KEY + 4 * (s + 1) + q], f2key(thr_new));
-                }
-                __syncthreads();
+            // another wave of the block is fetching: wait for the chunk to change
+            for (;;) {
+                __builtin_amdgcn_s_sleep(4);
+                unsigned long long now = 0;
+                if (lane == 0) now = __hip_atomic_load(chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane((int)(unsigned)(now >> 32)) != first) break;
+                if (++spins > CZ_FS_SPINS) return -1;   // (never seen; the tickets of the missing chunk leave their stage open: the waiters give up as well)
             }
         }
     };
 
-    int tk_next = 0;
-    if (tid == 0) tk_next = __hip_atomic_fetch_add(&fs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        if (tid == 0) l_tk = tk_next;
-        __syncthreads();
-        const int t = l_tk;
-        if (t >= total || aborted) break;
-        // (the next ticket travels while this tile is scored)
-        if (tid == 0) tk_next = __hip_atomic_fetch_add(&fs[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t = aborted ? -1 : draw();
+        if (t < 0) break;
         while (t >= sc.first[cur + 1]) ++cur;
-        const int u = t - sc.first[cur];
-        const int64_t tile = (int64_t)(cur == 0 ? u : u + u / sc.gm1[cur] + 1) * sc.stride[cur];
-        const int64_t row_base = tile * CZ_T + wave * 64;
-        float* rs = ring + (size_t)head * NQ * CZ_T;
+        if (cur != acc_stage) publish();
+        const int rel = t - sc.first[cur];
+        const int64_t row_base = quarter_rows(cur, rel);
+        float* rs = ring + head * NQ * 64;
 #pragma unroll 1
         for (int it = 0; it < 16; it += 2) {
             if constexpr (NQ > 1) asm volatile("" ::: "memory");
@@ -1853,20 +1944,21 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
             else
                 cz_sweep_pair_bf16<NQ, TT>(static_cast<const unsigned short*>(rows), qs, ra_, rb_, dpad, steps, sub, xn2, ma, mb);
             if (sub < NQ) {
-                rs[sub * CZ_T + wave * 64 + it * 4 + rg] = ma;
-                rs[sub * CZ_T + wave * 64 + it * 4 + rg + 4] = mb;
+                rs[sub * 64 + it * 4 + rg] = ma;
+                rs[sub * 64 + it * 4 + rg + 4] = mb;
             }
         }
-        if (tid == 0) {
+        if (lane == 0) {
             ring_stage[head] = cur;
-            ring_u[head] = u;
+            ring_rel[head] = rel;
         }
+        CZ_WAVE_LDS_SYNC();
         head = (head + 1) % CZ_FS_RING;
         ++npend;
-        __syncthreads();
         drain(npend == CZ_FS_RING);
     }
     drain(true);
+    publish();
 }
 
 // Work list of the band rescoring: the (query, part) items that exist, in query order -- one block, an exclusive

@@ -89,7 +89,7 @@ struct css_index {
     unsigned short* qh = nullptr; size_t qh_cap = 0;    // bf16 queries
     float* cthr = nullptr;    size_t cthr_cap = 0;
     int* cand_n = nullptr;    size_t cand_n_cap = 0;
-    int* cflags = nullptr;    size_t cflags_cap = 0;    // [nq_pad] flags | [nq_pad] flagged list | [1] count
+    int* cflags = nullptr;    size_t cflags_cap = 0;    // [nq_pad] flags | [nq_pad] flagged list | [1] count | [1] fix-up blocks done
     float* cand_s = nullptr;  size_t cand_s_cap = 0;
     uint32_t* cand_i = nullptr; size_t cand_i_cap = 0;
     int* cpace = nullptr;     size_t cpace_cap = 0;     // sibling pacing counters [stage][group]
@@ -104,7 +104,7 @@ struct css_index {
     int* cand_n2 = nullptr;   size_t cand_n2_cap = 0;
     float* cand_s2 = nullptr; size_t cand_s2_cap = 0;
     uint32_t* cand_i2 = nullptr; size_t cand_i2_cap = 0;
-    int* flagB = nullptr;     size_t flagB_cap = 0;      // [nq_pad] list | [1] count: queries left to the exact sweep
+    int* flagB = nullptr;     size_t flagB_cap = 0;      // [nq_pad] list | [1] count | [1] fix-up blocks done: queries left to the exact sweep
     // shadow-less indexes: bf16 rows of one row range at a time + the per-range top-k lists (search_noshadow_ranges)
     unsigned short* xh_tmp = nullptr; size_t xh_tmp_cap = 0;
     float* x8s_tmp = nullptr; size_t x8s_tmp_cap = 0;   // row scales when the scratch rows are int8
@@ -146,15 +146,11 @@ int grow(T** p, size_t* cap, size_t need) {
 // ------------------------------------------------------------------ ingest
 // One wave per row.  SYNTH: value = css_synth_normal(seed, (first_row+row)*dim + c).
 template <bool SYNTH>
-__global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ src, float* __restrict__ dst,
-                                                     float* __restrict__ norm2, int64_t n, int dim, int dpad,
-                                                     int normalize, uint64_t seed, int64_t first_row,
-                                                     unsigned short* __restrict__ dsth, int* __restrict__ maxn2,
-                                                     float* __restrict__ err2_out, unsigned char* __restrict__ dst8,
-                                                     float* __restrict__ dst8s) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+__device__ __forceinline__ void ingest_row(int64_t row, int lane, const float* __restrict__ src, float* __restrict__ dst,
+                                           float* __restrict__ norm2, int dim, int dpad, int normalize, uint64_t seed,
+                                           int64_t first_row, unsigned short* __restrict__ dsth, int* __restrict__ maxn2,
+                                           float* __restrict__ err2_out, unsigned char* __restrict__ dst8,
+                                           float* __restrict__ dst8s) {
     const float* s = SYNTH ? nullptr : src + row * (int64_t)dim;
     const uint64_t base = (uint64_t)((first_row + row) * (int64_t)dim);
     float ss = 0.f, amax = 0.f;
@@ -210,6 +206,18 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
     if (lane == 0 && maxn2 && s2 > __int_as_float(__hip_atomic_load(maxn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         atomicMax(maxn2, __float_as_int(s2));
 }
+template <bool SYNTH>
+__global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                     float* __restrict__ norm2, int64_t n, int dim, int dpad,
+                                                     int normalize, uint64_t seed, int64_t first_row,
+                                                     unsigned short* __restrict__ dsth, int* __restrict__ maxn2,
+                                                     float* __restrict__ err2_out, unsigned char* __restrict__ dst8,
+                                                     float* __restrict__ dst8s) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    ingest_row<SYNTH>(row, threadIdx.x & 63, src, dst, norm2, dim, dpad, normalize, seed, first_row, dsth, maxn2, err2_out, dst8,
+                      dst8s);
+}
 
 // ------------------------------------------------------------------ scan (small nq)
 // Block = 4 waves.  A wave instruction covers 4 rows: lane = 16*r + sub reads the
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
 // when it is zero (the usual case) -- no host round trip.  Otherwise the grid walks the flagged queries NQ at
 // a time; a block's lists are merged into one global list per query under an agent-scope lock (release /
 // acquire fences around plain loads and stores, MI355X_MICROARCH.md "Valid forms"); the lists were reset by
-// the kernel that flagged the query and k_fix_write turns them into D / I rows afterwards.
+// the kernel that flagged the query; the block that finishes last turns them into D / I rows.
 template <int NQ, int TT, int METRIC, bool FIX = false>
 __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict__ xb, const float* __restrict__ qpad,
                                                     int64_t ntotal, int T_rt, int k, int64_t groups_per_block,
@@ -230,7 +238,8 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
                                                     uint32_t* __restrict__ part_i, int nq_real_arg,
                                                     const uint32_t* __restrict__ mask,
                                                     const int* __restrict__ flag_list, const int* __restrict__ nflag_p,
-                                                    float* fix_s, uint32_t* fix_i, int* fix_lock) {
+                                                    float* fix_s, uint32_t* fix_i, int* fix_lock, int* fix_done,
+                                                    int64_t id_base, float* D, int64_t* I) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = TT > 0 ? TT : T_rt;  // float4 steps of 16 lanes: dpad = 64*T
     const int dpad = T * 64;
@@ -462,22 +471,33 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
         }
     }
   }
-}
-
-// Fix-up output: D / I rows of the flagged queries from their global lists (k_scan_small<FIX>).
-template <int METRIC>
-__global__ __launch_bounds__(64) void k_fix_write(const int* __restrict__ flag_list, const int* __restrict__ nflag_p,
-                                                  const float* __restrict__ fix_s, const uint32_t* __restrict__ fix_i,
-                                                  int k, int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I) {
-    const int nfl = *nflag_p;
-    for (int f = blockIdx.x; f < nfl; f += gridDim.x) {
-        const int q = flag_list[f];
-        for (int i = threadIdx.x; i < k; i += 64) {
-            const uint32_t id = fix_i[(size_t)q * k + i];
-            const float s = fix_s[(size_t)q * k + i];  // IP: dot; L2: -(squared distance)
-            const bool ok = id != kInvalidRow;
-            D[(size_t)q * k + i] = METRIC == CSS_METRIC_IP ? (ok ? s : -FLT_MAX) : (ok ? -s : FLT_MAX);
-            I[(size_t)q * k + i] = ok ? id_base + (int64_t)id : (int64_t)-1;
+    if constexpr (FIX) {
+        // The block that finishes last turns the global lists into the D / I rows of the flagged queries (a launch of
+        // its own until round 4: 9 us of every search for nothing, flagged queries being rare).  Every merge above
+        // ended with an agent-scope release under the list's lock; the counter add follows this block's last one.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(fix_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (int)gridDim.x - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lock[0] = last;
+        }
+        __syncthreads();
+        if (lock[0]) {
+            for (int f = 0; f < nfl; ++f) {
+                const int q = flag_list[f];
+                for (int i = tid; i < k; i += 256) {
+                    const uint32_t id = __hip_atomic_load(&fix_i[(size_t)q * k + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float s = __hip_atomic_load(&fix_s[(size_t)q * k + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // IP: dot; L2: -(squared distance)
+                    const bool ok = id != kInvalidRow;
+                    D[(size_t)q * k + i] = METRIC == CSS_METRIC_IP ? (ok ? s : -FLT_MAX) : (ok ? -s : FLT_MAX);
+                    I[(size_t)q * k + i] = ok ? id_base + (int64_t)id : (int64_t)-1;
+                }
+            }
         }
     }
 }
@@ -1513,7 +1533,8 @@ struct KnnEnv {
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
-    int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0: one launch per stage and select of that cascade (A/B runs) instead of k_sweep_cascade
+    int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
+    int fs_blocks = 0;      // CSS_KNN_FS_BLOCKS=n: at most n blocks of k_sweep_cascade per CU (A/B runs); 0 = what fits
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
     int dbg = 0;          // CSS_KNN_DBG: timing ablations of k_scan_coarse (results are wrong when set)
@@ -1537,7 +1558,8 @@ const KnnEnv& knn_env() {
             const int v = atoi(m);
             e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 4;
         }
-        if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : 1;
+        if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
+        if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
@@ -1559,7 +1581,7 @@ struct SweepGeom {
 template <int NQ, int TT, int METRIC, bool FIX>
 int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, const SweepGeom& sg,
                         hipStream_t st, const int* flag_list, const int* nflag, float* fix_s, uint32_t* fix_i,
-                        int* fix_lock) {
+                        int* fix_lock, float* D_dev, int64_t* I_dev) {
     const int T = ix->dpad / 64;
     const size_t lds = (size_t)NQ * ix->dpad * 4 + (size_t)NQ * k * 8 + NQ * 8 + (FIX ? (size_t)4 * k * 8 : 0);
     auto kern = k_scan_small<NQ, TT, METRIC, FIX>;
@@ -1567,7 +1589,9 @@ int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, in
     if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
     ProfScope ps(FIX ? "knn_fix_scan" : "knn_scan_small", st);
     hipLaunchKernelGGL(kern, dim3(sg.G), dim3(256), lds, st, (const float4*)ix->xb, qpad, ix->ntotal, T, k, sg.gpb, gthr,
-                       ix->part_s, ix->part_i, nq_real, ix->cur_mask, flag_list, nflag, fix_s, fix_i, fix_lock);
+                       ix->part_s, ix->part_i, nq_real, ix->cur_mask, flag_list, nflag, fix_s, fix_i, fix_lock,
+                       FIX ? const_cast<int*>(nflag) + 1 : (int*)nullptr,   // the blocks-done word sits behind the flagged count
+                       ix->id_base, D_dev, I_dev);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
@@ -1575,14 +1599,15 @@ int launch_scan_small_t(css_index* ix, const float* qpad, int nq_real, int k, in
 template <int NQ, bool FIX>
 int launch_scan_small_nq(css_index* ix, const float* qpad, int nq_real, int k, int* gthr, const SweepGeom& sg,
                          hipStream_t st, const int* flag_list = nullptr, const int* nflag = nullptr,
-                         float* fix_s = nullptr, uint32_t* fix_i = nullptr, int* fix_lock = nullptr) {
+                         float* fix_s = nullptr, uint32_t* fix_i = nullptr, int* fix_lock = nullptr, float* D_dev = nullptr,
+                         int64_t* I_dev = nullptr) {
     const bool ip = ix->metric == CSS_METRIC_IP;
     if (ix->dpad == 768) {
-        return ip ? launch_scan_small_t<NQ, 12, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock)
-                  : launch_scan_small_t<NQ, 12, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
+        return ip ? launch_scan_small_t<NQ, 12, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev)
+                  : launch_scan_small_t<NQ, 12, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev);
     }
-    return ip ? launch_scan_small_t<NQ, 0, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock)
-              : launch_scan_small_t<NQ, 0, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
+    return ip ? launch_scan_small_t<NQ, 0, CSS_METRIC_IP, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev)
+              : launch_scan_small_t<NQ, 0, CSS_METRIC_L2, FIX>(ix, qpad, nq_real, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev);
 }
 
 int grow_part(css_index* ix, size_t entries) {
@@ -1637,25 +1662,16 @@ int search_chunk_small(css_index* ix, int q0, int nqc, int k, const SweepGeom& s
 }
 
 // Device-side exact fix-up of the queries a candidate path flagged (overflowing buffer or band, band not closed):
-// two launches that return at once when nothing is flagged.  All pointers are already offset to the chunk's
+// one launch that returns at once when nothing is flagged (nflag[1]: its blocks-done counter, zeroed with the count).  All pointers are already offset to the chunk's
 // first query; the flagging kernel has reset gthr / fix lists / locks of every flagged query.
 int launch_fixup(css_index* ix, const float* qpad, int nq, int k, int* gthr, const int* flag_list, const int* nflag,
                  float* fix_s, uint32_t* fix_i, int* fix_lock, float* D_dev, int64_t* I_dev, const SweepGeom& sg,
                  hipStream_t st) {
     int rc;
-    if (sg.nq_sweep >= 8) rc = launch_scan_small_nq<8, true>(ix, qpad, 8, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
-    else if (sg.nq_sweep >= 2) rc = launch_scan_small_nq<2, true>(ix, qpad, 2, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
-    else rc = launch_scan_small_nq<1, true>(ix, qpad, 1, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock);
-    if (rc != CSS_OK) return rc;
-    const int grid = std::max(1, std::min(nq, 64));
-    if (ix->metric == CSS_METRIC_IP)
-        hipLaunchKernelGGL(k_fix_write<CSS_METRIC_IP>, dim3(grid), dim3(64), 0, st, flag_list, nflag, fix_s, fix_i, k,
-                           ix->id_base, D_dev, I_dev);
-    else
-        hipLaunchKernelGGL(k_fix_write<CSS_METRIC_L2>, dim3(grid), dim3(64), 0, st, flag_list, nflag, fix_s, fix_i, k,
-                           ix->id_base, D_dev, I_dev);
-    CSS_LAUNCH_CHECK();
-    return CSS_OK;
+    if (sg.nq_sweep >= 8) rc = launch_scan_small_nq<8, true>(ix, qpad, 8, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev);
+    else if (sg.nq_sweep >= 2) rc = launch_scan_small_nq<2, true>(ix, qpad, 2, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev);
+    else rc = launch_scan_small_nq<1, true>(ix, qpad, 1, k, gthr, sg, st, flag_list, nflag, fix_s, fix_i, fix_lock, D_dev, I_dev);
+    return rc;
 }
 
 // workspaces shared by the candidate paths: thresholds, candidate buffers, flags, fix-up lists for nq_pad queries
@@ -1666,7 +1682,7 @@ int grow_candidate_ws(css_index* ix, size_t nq_pad, int k) {
     if ((rc = grow(&ix->rs_work, &ix->rs_work_cap, 1 + (size_t)nq_pad * CZ_PARTS)) != CSS_OK) return rc;
     ix->last_nflag = nullptr;
     ix->last_nswept = nullptr;
-    if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 1)) != CSS_OK) return rc;
+    if ((rc = grow(&ix->cflags, &ix->cflags_cap, 2 * nq_pad + 2)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_s, &ix->cand_s_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
     if ((rc = grow(&ix->cand_i, &ix->cand_i_cap, nq_pad * CZ_CAP)) != CSS_OK) return rc;
     if ((rc = grow(&ix->fix_lock, &ix->fix_lock_cap, nq_pad)) != CSS_OK) return rc;
@@ -1762,10 +1778,13 @@ int launch_final_select(css_index* ix, int nq, int k, EpsSet e1, EpsSet e2, bool
     hipLaunchKernelGGL(k_coarse_select<true>, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr, flags,
                        nflag, flag_list, qnorm2, ix->maxn2, eps_rel, l2, k, closed_n, gthr, qerr2, measured, ix->fix_s, ix->fix_i, ix->fix_lock,
                        exact_k ? qpad : (const float*)nullptr, exact_k ? (const float*)ix->xb : (const float*)nullptr, ix->dpad);
-    hipLaunchKernelGGL(k_rescore_plan, dim3(1), dim3(1024), 0, st, (const int*)ix->cand_n, nq, ix->rs_work, ix->rs_work + 1);
+    // (a work list of the live parts pays from a few dozen queries on; a handful of queries launch all their parts)
+    const bool plan = nq > 16;
+    if (plan) hipLaunchKernelGGL(k_rescore_plan, dim3(1), dim3(1024), 0, st, (const int*)ix->cand_n, nq, ix->rs_work, ix->rs_work + 1);
     hipLaunchKernelGGL(k_rescore_parts<false>, dim3(std::min(kRescoreGrid, nq * CZ_PARTS)), dim3(256), 0, st, ix->cand_s,
                        ix->cand_i, ix->cand_n, CZ_CAP, nq, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, l2, qpad,
-                       ix->xb, ix->dpad, (const int*)ix->rs_work, (const int*)(ix->rs_work + 1));
+                       ix->xb, ix->dpad, plan ? (const int*)ix->rs_work : (const int*)nullptr,
+                       plan ? (const int*)(ix->rs_work + 1) : (const int*)nullptr);
     hipLaunchKernelGGL(k_coarse_final, dim3(nq), dim3(256), 0, st, ix->cand_s, ix->cand_i, ix->cand_n, flags, qnorm2, ix->maxn2,
                        e2.eps_rel, l2, k, qpad, ix->dpad, ix->id_base, D_dev, I_dev, thr2, qh2, f2, e2.qerr2, e2.measured);
     CSS_LAUNCH_CHECK();
@@ -1807,7 +1826,8 @@ int launch_scan_split_rescore(css_index* ix, int q0, int nq, int k, float* D_dev
         CSS_HIP_TRY(hipMemsetAsync(qpad + (size_t)nq * ix->dpad, 0, (size_t)(nq_pad - nq) * ix->dpad * 4, st));
     hipLaunchKernelGGL(k_fill_int, dim3((nq_pad + 255) / 256), dim3(256), 0, st, gthr, nq_pad, host_f2key(-INFINITY));
     hipLaunchKernelGGL(k_coarse_init, dim3((nq_pad + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags, nflag,
-                       nq, nq_pad, 0, (int*)nullptr, 0, (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (int*)nullptr);
+                       nq, nq_pad, 0, (int*)nullptr, 0, (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (int*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0, 0);
     const int64_t ne = (int64_t)nq_pad * ix->dpad;
     hipLaunchKernelGGL(k_split_queries, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, qpad, ix->qsplit,
                        (int64_t)nq_pad, ix->dpad);
@@ -1960,6 +1980,8 @@ int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSch
     // the very end, load the queries and find nothing to do); nothing depends on the blocks being co-resident
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = std::min(per_cu, 3);   // (12 waves per CU already draw the whole HBM rate: 2 / 3 / 4 blocks 1.305 / 1.302 / 1.316 ms at 10 M rows)
+    if (const int cap = knn_env().fs_blocks) per_cu = std::min(per_cu, cap);
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * std::min(per_cu, 8), (sc.first[sc.nstage] + 3) / 4);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, I8 ? (const void*)ix->x8 : (const void*)ix->xh,
                        I8 ? (const float*)ix->x8s : (const float*)nullptr, qpad, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
@@ -1988,8 +2010,11 @@ inline int coarse_max_chunk(const css_index* ix) { return std::min(4096, coarse_
 // use_i8: which shadow rows this SEARCH reads, decided once by the caller (search_dev_enqueue / search_noshadow_ranges:
 // the per-index feedback is consulted once per search, not per chunk); record_fb: this is the search's last chunk, whose
 // flagged count is what the feedback sees.
+// q_raw != null (sweep only): the raw query rows, still to be prepared (normalize_q as in search_dev_enqueue) -- the init
+// launch of the cascade does it.
 int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64_t* I_dev, hipStream_t st,
-                       const SweepGeom& sg, bool sweep, bool use_i8, bool record_fb) {
+                       const SweepGeom& sg, bool sweep, bool use_i8, bool record_fb, const float* q_raw = nullptr,
+                       int normalize_q = 0) {
     const KnnEnv& env = knn_env();
     const float* qpad = ix->qpad + (size_t)q0 * ix->dpad;
     const float* qnorm2 = ix->qnorm2 + q0;
@@ -2040,7 +2065,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         if ((rc = grow(&ix->cand_n2, &ix->cand_n2_cap, (size_t)f2 * CZ_NS)) != CSS_OK) return rc;
         if ((rc = grow(&ix->cand_s2, &ix->cand_s2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
         if ((rc = grow(&ix->cand_i2, &ix->cand_i2_cap, (size_t)f2 * CZ_CAP2)) != CSS_OK) return rc;
-        if ((rc = grow(&ix->flagB, &ix->flagB_cap, (size_t)nq_pad + 1)) != CSS_OK) return rc;
+        if ((rc = grow(&ix->flagB, &ix->flagB_cap, (size_t)nq_pad + 2)) != CSS_OK) return rc;
         flag_listB = ix->flagB;
         nflagB = ix->flagB + nq_pad;
         ix->last_nswept = nflagB;
@@ -2082,7 +2107,10 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     }
     const int64_t n0 = (ntiles + sched[0].stride - 1) / sched[0].stride;
     // 1..4 queries: the stages and the selects between them as ONE launch (k_sweep_cascade), quarter tiles as tickets in stage order
-    bool fused = sweep && env.sweep_fused && (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 28;
+    // (measured, ms one launch / one per stage: 10 M rows, 1 query k = 10 1.35 / 1.41, k = 100 1.40 / 1.56, 2 queries 1.40 /
+    // 1.47, 4 queries 2.68 / 2.69; 100 k rows: 0.085 / 0.095, 0.118 / 0.125, but 2 queries 0.117 / 0.111, 4: 0.186 / 0.155)
+    bool fused = sweep && env.sweep_fused && (env.sweep_fused == 2 || nq == 1 || ix->ntotal >= 1000000) &&
+                 (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 28;
     FsSched fsched{};
     if (fused) {
         fsched.nstage = (int)sched.size();
@@ -2122,7 +2150,8 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         hipLaunchKernelGGL(k_coarse_init, dim3((ninit + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T), use_pace ? ix->cpace : (int*)nullptr, npace,
                            pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2,
-                           fused ? ix->fs_state : (int*)nullptr);
+                           fused ? ix->fs_state : (int*)nullptr, q_raw, ix->qpad + (size_t)q0 * ix->dpad, ix->qnorm2 + q0,
+                           ix->qerr2 + q0, ix->dim, ix->dpad, normalize_q);
         CSS_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
@@ -2455,8 +2484,16 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->qerr2, &ix->qerr2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
+    // 1..4 queries through the sweep cascade: its init launch prepares the query rows as well (one launch less in front
+    // of a 1.4 ms search).  Which shadow rows a search reads is decided once (the per-index int8 feedback counts searches).
+    const bool sweep_wanted = ix->ntotal > 0 && nq <= 4 && k <= CSS_KERNEL_MAX_K && env.batch == 0 &&
+                              (ix->xh != nullptr || ix->x8 != nullptr) &&
+                              (ix->search_mode == CSS_SEARCH_COARSE ||
+                               (ix->search_mode == CSS_SEARCH_AUTO && (k > 32 || ix->ntotal >= 100000)));
+    const bool sweep_i8 = sweep_wanted && ix->x8 != nullptr && sweep_uses_i8(ix);
+    const bool sweep_path = sweep_wanted && (sweep_i8 || ix->xh != nullptr);
     // query prep: same row kernel as ingest (normalise, zero pad, squared norm)
-    {
+    if (!sweep_path) {
         const int64_t blocks = (nq + 3) / 4;
         hipLaunchKernelGGL(k_ingest_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, q_dev, ix->qpad,
                            ix->qnorm2, nq, ix->dim, ix->dpad, normalize_q, 0ull, 0ll, (unsigned short*)nullptr,
@@ -2490,9 +2527,9 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     // index without shadow rows (bf16 scratch ranges for batches, the exact kernels for a few queries).
     if (want_candidates && (ix->xh != nullptr || ix->x8 != nullptr)) {
         const bool sweep = nq <= 4;  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
-        const bool use_i8 = ix->x8 != nullptr && (sweep ? sweep_uses_i8(ix) : batch_i8_wanted(ix, k, ix->ntotal, nq));
+        const bool use_i8 = ix->x8 != nullptr && (sweep ? sweep_i8 : batch_i8_wanted(ix, k, ix->ntotal, nq));
         if (use_i8 || ix->xh != nullptr) {
-            if (sweep) return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true, use_i8, true);
+            if (sweep) return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true, use_i8, true, q_dev, normalize_q);
             const int chunk = coarse_max_chunk(ix);
             for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
                 const int nqc = (int)std::min<int64_t>(chunk, nq - q0);

@@ -157,18 +157,25 @@ constexpr int CZ_FS_KEYWORDS = 4 * CZ_FS_MAXST * CZ_FS_COPIES, CZ_FS_WORDS = CZ_
 // thr = -inf (real queries) / +inf (padding), counters and flags cleared; with them (one launch instead of three)
 // the sibling-pacing counters of the scan stages and the counters / thresholds of the second pass: slots that no
 // flagged query claims take part in that scan with thr2 = +inf, i.e. without ever appending
+// q_raw != null (the 1..4-query sweep): this launch also prepares the query rows -- normalise, zero pad, squared norm:
+// ingest_row, one wave per query, the arithmetic of the separate k_ingest_rows launch it replaces
 __global__ void k_coarse_init(float* thr, int* cand_n, int* flags, int* nflag, int nq, int nq_pad, int n0rows,
                               int* __restrict__ pace, int npace, int* __restrict__ cand_n2, float* __restrict__ thr2,
-                              int* __restrict__ nflagB, int f2max, int* __restrict__ fs) {
+                              int* __restrict__ nflagB, int f2max, int* __restrict__ fs, const float* __restrict__ q_raw,
+                              float* __restrict__ q_out, float* __restrict__ qnorm2_out, float* __restrict__ qerr2_out,
+                              int dim, int dpad, int normalize_q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q_raw != nullptr && (i >> 6) < nq)
+        ingest_row<false>(i >> 6, i & 63, q_raw, q_out, qnorm2_out, dim, dpad, normalize_q, 0ull, 0ll, (unsigned short*)nullptr,
+                          (int*)nullptr, qerr2_out, (unsigned char*)nullptr, (float*)nullptr);
     // k_sweep_cascade: counters zero, stage 0 open (threshold -inf), every later stage unpublished
     if (fs != nullptr && i < CZ_FS_KEYWORDS) {
         fs[CZ_FS_KEY + i] = (i & (4 * CZ_FS_MAXST - 1)) < 4 ? f2key(-INFINITY) : CZ_FS_SENT;
         if (i < 2 + CZ_FS_MAXST) fs[i * CZ_FS_LINE] = 0;
     }
-    if (i == 0) {
-        *nflag = 0;
-        if (nflagB) *nflagB = 0;
+    if (i == 0) {   // (word 1 behind a count: the blocks-done counter of the exact fix-up, k_scan_small<FIX>)
+        nflag[0] = nflag[1] = 0;
+        if (nflagB) nflagB[0] = nflagB[1] = 0;
     }
     if (i < npace) pace[i] = 0;
     if (i < f2max) {
@@ -1057,10 +1064,12 @@ __device__ __forceinline__ void cz_sweep_pair_bf16(const unsigned short* __restr
 
 // One step of the int8 sweep (layout and arithmetic: k_sweep_coarse_i8 below): rows ra_ / rb_ against the NQ permuted
 // queries in LDS (qlen floats each; my_off = 128 * sum of the query's elements for lane `sub`'s query).
-template <int NQ, int TT>
+// QREG (one query, compile-time steps): the lane's 4 * TT float4 of the query come in registers (qr) instead of LDS.
+template <int NQ, int TT, bool QREG = false>
 __device__ __forceinline__ void cz_sweep_pair_i8(const unsigned char* __restrict__ x8, const float* __restrict__ x8s, const float* qs,
                                                  int qlen, float my_off, int64_t ra_, int64_t rb_, int dpad, int chunks, int steps,
-                                                 int sub, const float* __restrict__ xn2, float& ma, float& mb) {
+                                                 int sub, const float* __restrict__ xn2, float& ma, float& mb,
+                                                 const float4* qr = nullptr) {
     const uint4* pa = reinterpret_cast<const uint4*>(x8 + (size_t)ra_ * dpad) + sub;
     const uint4* pb = reinterpret_cast<const uint4*>(x8 + (size_t)rb_ * dpad) + sub;
     const float scA = x8s[ra_], scB = x8s[rb_];
@@ -1074,7 +1083,8 @@ __device__ __forceinline__ void cz_sweep_pair_i8(const unsigned char* __restrict
         const unsigned wb[4] = {(VB_).x ^ 0x80808080u, (VB_).y ^ 0x80808080u, (VB_).z ^ 0x80808080u, (VB_).w ^ 0x80808080u}; \
         _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                               \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
-                const float4 qv = *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
+                const float4 qv = QREG ? qr[4 * (T_) + r]                                                \
+                                       : *reinterpret_cast<const float4*>(qs + j * qlen + 256 * (T_) + 64 * r + 4 * sub); \
                 sa[j] = fmaf((float)(wa[r] & 0xFFu), qv.x, sa[j]);                                     \
                 sa[j] = fmaf((float)((wa[r] >> 8) & 0xFFu), qv.y, sa[j]);                              \
                 sa[j] = fmaf((float)((wa[r] >> 16) & 0xFFu), qv.z, sa[j]);                             \
@@ -1727,6 +1737,16 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
     }
     __syncthreads();   // the last block barrier: from here on every wave runs on its own
     const float my_off = (I8 && sub < NQ) ? qoff[sub < NQ ? sub : 0] : 0.f;
+#ifndef CZ_FS_QREG
+#define CZ_FS_QREG 1
+#endif
+    // one int8 query: its 48 floats per lane stay in registers (as the stage kernels' compiler-hoisted copy did)
+    constexpr bool kQReg = CZ_FS_QREG && I8 && NQ == 1 && TT > 0;
+    float4 qr[kQReg ? 4 * TT : 1];
+    if constexpr (kQReg) {
+#pragma unroll
+        for (int i = 0; i < 4 * TT; ++i) qr[i] = *reinterpret_cast<const float4*>(qs + 256 * (i >> 2) + 64 * (i & 3) + 4 * sub);
+    }
     const int total = sc.first[sc.nstage];
     const int long_from = sc.first[sc.nstage > 2 ? sc.nstage - 2 : 0];   // the two long stages start here
     const int* keys = fs + CZ_FS_KEY + ((int)blockIdx.x % CZ_FS_COPIES) * 4 * CZ_FS_MAXST;   // this block's copy of the key words
@@ -1939,8 +1959,8 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
             const int64_t ra_ = rowA < ntotal ? rowA : ntotal - 1, rb_ = rowB < ntotal ? rowB : ntotal - 1;
             float ma, mb;
             if constexpr (I8)
-                cz_sweep_pair_i8<NQ, TT>(static_cast<const unsigned char*>(rows), x8s, qs, qlen, my_off, ra_, rb_, dpad, chunks,
-                                         steps, sub, xn2, ma, mb);
+                cz_sweep_pair_i8<NQ, TT, kQReg>(static_cast<const unsigned char*>(rows), x8s, qs, qlen, my_off, ra_, rb_, dpad,
+                                                chunks, steps, sub, xn2, ma, mb, qr);
             else
                 cz_sweep_pair_bf16<NQ, TT>(static_cast<const unsigned short*>(rows), qs, ra_, rb_, dpad, steps, sub, xn2, ma, mb);
             if (sub < NQ) {
@@ -2044,6 +2064,8 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
                                                       const float* __restrict__ qerr2, int measured) {
     __shared__ float s[CZ_CAP];
     __shared__ uint32_t id[CZ_CAP];
+    __shared__ unsigned hist[256];
+    __shared__ int sel[2], cnt;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int R = min(cand_n[(size_t)(q) * CZ_NS], CZ_CAP);
     int P = 2;
@@ -2051,9 +2073,60 @@ __global__ __launch_bounds__(256) void k_coarse_final(const float* __restrict__ 
     for (int i = tid; i < P; i += 256) {
         s[i] = i < R ? cand_s[(size_t)q * CZ_CAP + i] : -INFINITY;
         id[i] = i < R ? cand_i[(size_t)q * CZ_CAP + i] : kInvalidRow;
-        if (s[i] == -INFINITY) id[i] = kInvalidRow;   // (dropped by the rescoring)
+        if (!(s[i] > -INFINITY)) {   // dropped by the rescoring (or a NaN score: the ranks below need a total order)
+            s[i] = -INFINITY;
+            id[i] = kInvalidRow;
+        }
     }
-    cz_bitonic(s, id, P, tid);
+    // Only the k best matter.  The usual band (k + a few dozen to several hundred rows): the k-th best exact score by
+    // radix selection, the entries that reach it (k, more on ties) move to the upper half of the arrays, each of them
+    // counts the ones in front of it and lands at its rank -- ~20 barriers instead of the 36-78 rounds of a bitonic sort
+    // of the whole band.
+    bool sorted = false;
+    if (R <= CZ_CAP / 2) {
+        float* s2 = s + CZ_CAP / 2;
+        uint32_t* id2 = id + CZ_CAP / 2;
+        __syncthreads();
+        const int kk = min(k, R);
+        const float Tk = kk > 0 ? cz_kth_largest(s, R, kk, hist, sel, tid) : -INFINITY;
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        for (int i = tid; i < R; i += 256)
+            if (s[i] >= Tk) {
+                const int pos = atomicAdd(&cnt, 1);
+                s2[pos] = s[i];
+                id2[pos] = id[i];
+            }
+        __syncthreads();
+        const int m = cnt;   // >= kk
+        if (m <= 512) {
+            for (int i = tid; i < m; i += 256) {
+                const float si = s2[i];
+                const uint32_t ii = id2[i];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) {
+                    const float sj = s2[j];
+                    const uint32_t ij = id2[j];
+                    rank += (sj > si || (sj == si && (ij < ii || (ij == ii && j < i)))) ? 1 : 0;
+                }
+                s[rank] = si;     // (ranks < m <= R; the band's own entries there are no longer needed:
+                id[rank] = ii;    // every thread has passed the barrier behind the selection's last read of them)
+            }
+            __syncthreads();
+            sorted = true;
+        }
+    }
+    if (!sorted) {
+        for (int i = tid; i < P; i += 256) {   // (the selection leaves s / id as they were unless it sorted)
+            s[i] = i < R ? cand_s[(size_t)q * CZ_CAP + i] : -INFINITY;
+            id[i] = i < R ? cand_i[(size_t)q * CZ_CAP + i] : kInvalidRow;
+            if (!(s[i] > -INFINITY)) {
+                s[i] = -INFINITY;
+                id[i] = kInvalidRow;
+            }
+        }
+        cz_bitonic(s, id, P, tid);
+    }
     for (int i = tid; i < k; i += 256) {
         const bool ok = i < R && id[i] != kInvalidRow;
         D[(size_t)q * k + i] = l2 ? (ok ? -s[i] : FLT_MAX) : (ok ? s[i] : -FLT_MAX);

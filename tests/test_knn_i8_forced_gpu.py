@@ -19,3 +19,18 @@ def test_parity_suite_with_the_int8_scan_forced():
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 failed:\n{tail}\n{r.stderr[-2000:]}"
     assert " passed" in tail
+
+
+@pytest.mark.gpu
+def test_parity_suite_with_the_one_launch_cascade_forced():
+    """1..4 queries: the sweep cascade as ONE persistent launch (k_sweep_cascade) is chosen by itself for a single query and, for
+    2..4 queries, only from 1 M rows on (css_index.hip: launch_scan_coarse); CSS_KNN_SWEEP_FUSED=2 sends every few-query
+    search of the parity suite through it -- masks, L2, ragged sizes, duplicates, k > 128 passes included -- and
+    CSS_KNN_SWEEP_FUSED=0 keeps the launch-per-stage cascade it replaces under the same tests."""
+    for mode in ("2", "0"):
+        env = dict(os.environ, CSS_KNN_SWEEP_FUSED=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
+                            "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+        tail = "\n".join(r.stdout.splitlines()[-15:])
+        assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SWEEP_FUSED={mode} failed:\n{tail}\n{r.stderr[-2000:]}"
+        assert " passed" in tail

@@ -1534,6 +1534,7 @@ struct KnnEnv {
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
+    int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
     int fs_blocks = 0;      // CSS_KNN_FS_BLOCKS=n: at most n blocks of k_sweep_cascade per CU (A/B runs); 0 = what fits
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
     int pacing = 1;       // CSS_KNN_PACE=0: no sibling pacing in k_scan_coarse (A/B runs)
@@ -1560,6 +1561,7 @@ const KnnEnv& knn_env() {
         }
         if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
+        if (const char* m = getenv("CSS_KNN_FS_SPINS")) e.fs_spins = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
@@ -1986,7 +1988,8 @@ int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSch
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, I8 ? (const void*)ix->x8 : (const void*)ix->xh,
                        I8 ? (const float*)ix->x8s : (const float*)nullptr, qpad, ix->cand_s, ix->cand_i, ix->cand_n, ix->cthr,
                        flags, ix->ntotal, ix->dpad, nq, sc, ix->fs_state, ix->cur_mask,
-                       ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr, qnorm2, (const int*)ix->maxn2, eps_rel, l2, k, measured);
+                       ix->metric == CSS_METRIC_L2 ? ix->xnorm2 : nullptr, qnorm2, (const int*)ix->maxn2, eps_rel, l2, k, measured,
+                       knn_env().fs_spins);
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }

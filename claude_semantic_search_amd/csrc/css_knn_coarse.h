@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
 // Visibility across CUs / XCDs (cdna_hip_programming.md Guideline 16): every shared word is an agent-scope atomic;
 // candidate entries are write-through (sc1) stores, drained by the storing wave before its counter add; the selecting
 // wave takes one agent-scope acquire before it loads them (with sc1 loads).
-constexpr int CZ_FS_SPINS = 1 << 18;       // polls (~0.5 us apart) before a wave gives up: ~0.1 s
+constexpr int CZ_FS_SPINS = 1 << 18;       // polls (~0.5 us apart) before a wave gives up: ~0.1 s (kernel argument: tests pass 0)
 // dynamic LDS of k_sweep_cascade in floats: queries | 4 offsets | 4 (the block's chunk word) | 4 waves x (ring | 256 bins | 2 ring arrays)
 __host__ __device__ constexpr int cz_fs_lds_floats(int nq_t, int qlen) {
     return nq_t * qlen + 4 + 4 + 4 * (CZ_FS_RING * nq_t * 64 + 256 + 2 * CZ_FS_RING);
@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
                                                        int nq, FsSched sc, int* fs, const uint32_t* __restrict__ mask,
                                                        const float* __restrict__ xn2, const float* __restrict__ qnorm2,
                                                        const int* __restrict__ maxn2_bits, float eps_rel, int l2, int k,
-                                                       int measured) {
+                                                       int measured, int spin_limit) {
     // queries (layout of the stage kernels) | [4] offsets | per wave: ring, bins, ring bookkeeping (all of it in the
     // dynamic region: statics in front of it would shift its 16-byte alignment)
     extern __shared__ __attribute__((aligned(16))) float qs[];
@@ -1856,10 +1856,13 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
                     }
                 }
                 ok = __builtin_amdgcn_readfirstlane(ok);
-                if (ok == 0 && force && ++spins > CZ_FS_SPINS) {   // (never seen: see the kernel's header)
+                if (ok == 0 && force && ++spins > spin_limit) {   // (never seen outside the tests: see the kernel's header)
                     if (lane == 0) {
                         CZ_AT_ST(&fs[CZ_FS_ABORT], 1);
-                        for (int q = 0; q < nq; ++q) CZ_AT_ST(&flags[q], 1);
+                        for (int q = 0; q < nq; ++q) {
+                            CZ_AT_ST(&flags[q], 1);                        // -> the exact fix-up answers the query
+                            CZ_AT_ST(&cand_n[(size_t)q * CZ_NS], 0);       // (stage-0 slots may never be written now)
+                        }
                     }
                     ok = -1;
                 }
@@ -1939,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_sweep_cascade(const void* __restrict__ 
                 unsigned long long now = 0;
                 if (lane == 0) now = __hip_atomic_load(chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__builtin_amdgcn_readfirstlane((int)(unsigned)(now >> 32)) != first) break;
-                if (++spins > CZ_FS_SPINS) return -1;   // (never seen; the tickets of the missing chunk leave their stage open: the waiters give up as well)
+                if (++spins > spin_limit) return -1;   // (never seen; the tickets of the missing chunk leave their stage open: the waiters give up as well)
             }
         }
     };

@@ -34,3 +34,17 @@ def test_parity_suite_with_the_one_launch_cascade_forced():
         tail = "\n".join(r.stdout.splitlines()[-15:])
         assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SWEEP_FUSED={mode} failed:\n{tail}\n{r.stderr[-2000:]}"
         assert " passed" in tail
+
+
+@pytest.mark.gpu
+def test_one_launch_cascade_that_gives_up_still_answers_exactly():
+    """k_sweep_cascade bounds every wait: a wave that gives up flags the queries and the device-side exact fix-up answers
+    them.  CSS_KNN_FS_SPINS=0 makes every wave give up the first time it would have to wait for a threshold, so the
+    few-query searches of the parity suite all end in that fall-back -- slow, and still exact."""
+    env = dict(os.environ, CSS_KNN_SWEEP_FUSED="2", CSS_KNN_FS_SPINS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "known_answers or k_values or ragged or mask or l2 or duplicate"],
+                       cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, f"test_knn_gpu.py with waits that give up at once failed:\n{tail}\n{r.stderr[-2000:]}"
+    assert " passed" in tail

@@ -30,7 +30,7 @@ if [ "$2" = "full" ]; then
 fi
 # --- kernel-trace stats, one leg each ---------------------------------------------------------------------------
 stats headline $LIGHT --legs none || exit 2                       # k_scan_coarse8<false,true,false,4096,true>: 1000 q x 10 M
-stats nq1 $LIGHT --legs nq1 --steps 2 --warmup 1 || exit 3        # k_sweep_coarse_i8<1,3,true>: single query, k = 10 and k' = 100
+stats nq1 $LIGHT --legs nq1 --steps 2 --warmup 1 || exit 3        # k_sweep_cascade<1,3,true>: single query, k = 10 and k' = 100
 stats exact $LIGHT --legs exact --steps 2 --warmup 1 || exit 4    # k_scan_small<1,..> (nq = 1) and k_scan_mfma (256 queries)
 stats encoder --only-encoder --enc-fixed-only --no-cpu-baseline --enc-steps 5 || exit 5
 # --- HBM-side traffic (FETCH_SIZE, WRITE_SIZE: separate passes) -----------------------------------------------------

@@ -1980,8 +1980,11 @@ int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSch
     if (lds > 48 * 1024 && (rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
     // as many blocks as the chip holds at once (a wave leaves only when the tickets run out: more blocks would start at
     // the very end, load the queries and find nothing to do); nothing depends on the blocks being co-resident
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    static int per_cu_of[64];   // (asked once per device and instantiation: the answer depends on nothing else here)
+    int& per_cu_cached = per_cu_of[ix->device & 63];
+    if (per_cu_cached == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, lds) != hipSuccess || per_cu_cached < 1))
+        per_cu_cached = 1;
+    int per_cu = per_cu_cached;
     per_cu = std::min(per_cu, 3);   // (12 waves per CU already draw the whole HBM rate: 2 / 3 / 4 blocks 1.305 / 1.302 / 1.316 ms at 10 M rows)
     if (const int cap = knn_env().fs_blocks) per_cu = std::min(per_cu, cap);
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * std::min(per_cu, 8), (sc.first[sc.nstage] + 3) / 4);

@@ -83,7 +83,11 @@ struct css_index {
     unsigned short* qsplit = nullptr; size_t qsplit_cap = 0;  // bf16 (h,l) pairs
     int* gthr = nullptr;      size_t gthr_cap = 0;      // ints
     float* part_s = nullptr;  uint32_t* part_i = nullptr; size_t part_cap = 0;  // entries
-    float* out_d = nullptr;   int64_t* out_i = nullptr; size_t out_cap = 0;     // entries
+    int64_t* out_i = nullptr; size_t out_cap = 0;      // entries (12 bytes each); a call's rows: [nq * k ids | nq * k scores]
+    // pinned staging of the host API for the reference's call shape (one query, k' = 100: 3 KB in, 1.2 KB out): pageable
+    // copies of that size cost a staging pass and a wait each
+    char* h_stage = nullptr;
+    static constexpr size_t kHostStage = 64 * 1024;   // bytes, each way
     float* stage = nullptr;   size_t stage_cap = 0;     // floats
     // coarse + rescore path (css_knn_coarse.h)
     unsigned short* qh = nullptr; size_t qh_cap = 0;    // bf16 queries
@@ -2637,11 +2641,12 @@ int css_index_free(css_index* ix) {
             (void)hipHostFree(f->h_nflag);
         }
     void* ptrs[] = {ix->xb, ix->xnorm2, ix->xh, ix->x8, ix->x8s, ix->maxn2, ix->q_raw, ix->qpad, ix->qnorm2, ix->qerr2, ix->qerr2_i8, ix->qscale, ix->gthr, ix->qsplit,
-                    ix->part_s, ix->part_i, ix->out_d, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
+                    ix->part_s, ix->part_i, ix->out_i, ix->stage, ix->qh, ix->cthr, ix->cand_n,
                     ix->cflags, ix->cand_s, ix->cand_i, ix->cpace, ix->fs_state, ix->mask_ws, ix->excl_ws, ix->fix_s, ix->fix_i, ix->fix_lock,
                     ix->qh2, ix->thr2, ix->rs_work, ix->cand_n2, ix->cand_s2, ix->cand_i2, ix->flagB, ix->xh_tmp, ix->x8s_tmp, ix->rng_d, ix->rng_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);  // (hipFree waits for the device: nothing enqueued by a _dev call still runs)
+    if (ix->h_stage) (void)hipHostFree(ix->h_stage);
     if (ix->ingest_ev) (void)hipEventDestroy(ix->ingest_ev);
     if (ix->ws_ev) (void)hipEventDestroy(ix->ws_ev);
     (void)hipStreamDestroy(ix->stream);
@@ -2953,16 +2958,17 @@ int css_index_search_masked(css_index* ix, const float* q_host, int64_t nq, int 
     {
         size_t need = (size_t)nq * k;
         if (need > ix->out_cap) {
-            if (ix->out_d) CSS_HIP_TRY(hipFree(ix->out_d));
             if (ix->out_i) CSS_HIP_TRY(hipFree(ix->out_i));
-            ix->out_d = nullptr;
             ix->out_i = nullptr;
             ix->out_cap = 0;
-            CSS_HIP_TRY(hipMalloc((void**)&ix->out_d, need * sizeof(float)));
-            CSS_HIP_TRY(hipMalloc((void**)&ix->out_i, need * sizeof(int64_t)));
+            CSS_HIP_TRY(hipMalloc((void**)&ix->out_i, need * (sizeof(int64_t) + sizeof(float))));
             ix->out_cap = need;
         }
     }
+    const size_t q_bytes = (size_t)nq * ix->dim * 4, out_bytes = (size_t)nq * k * 12;
+    const bool staged = q_bytes <= css_index::kHostStage && out_bytes <= css_index::kHostStage;
+    if (staged && ix->h_stage == nullptr)
+        CSS_HIP_TRY(hipHostMalloc((void**)&ix->h_stage, 2 * css_index::kHostStage, hipHostMallocDefault));
     const uint32_t* mask_dev = nullptr;
     if (allow_bits_host && ix->ntotal > 0) {
         const size_t words = (size_t)((ix->ntotal + 31) / 32);
@@ -2970,10 +2976,24 @@ int css_index_search_masked(css_index* ix, const float* q_host, int64_t nq, int 
         CSS_HIP_TRY(hipMemcpyAsync(ix->mask_ws, allow_bits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
         mask_dev = ix->mask_ws;
     }
-    CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, q_host, (size_t)nq * ix->dim * 4, hipMemcpyHostToDevice, ix->stream));
-    if ((rc = search_any_k(ix, ix->q_raw, nq, k, normalize_q, mask_dev, ix->out_d, ix->out_i, ix->stream)) != CSS_OK)
-        return rc;
-    CSS_HIP_TRY(hipMemcpyAsync(D_host, ix->out_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    // (the output rows of THIS call sit at the front of the allocation: ids of nq * k entries, then their scores)
+    float* const d_out = reinterpret_cast<float*>(ix->out_i + (size_t)nq * k);
+    if (staged) {
+        memcpy(ix->h_stage, q_host, q_bytes);
+        CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, ix->h_stage, q_bytes, hipMemcpyHostToDevice, ix->stream));
+    } else {
+        CSS_HIP_TRY(hipMemcpyAsync(ix->q_raw, q_host, q_bytes, hipMemcpyHostToDevice, ix->stream));
+    }
+    if ((rc = search_any_k(ix, ix->q_raw, nq, k, normalize_q, mask_dev, d_out, ix->out_i, ix->stream)) != CSS_OK) return rc;
+    if (staged) {   // one copy into pinned memory, one wait
+        char* back = ix->h_stage + css_index::kHostStage;
+        CSS_HIP_TRY(hipMemcpyAsync(back, ix->out_i, out_bytes, hipMemcpyDeviceToHost, ix->stream));
+        CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
+        memcpy(I_host, back, (size_t)nq * k * 8);
+        memcpy(D_host, back + (size_t)nq * k * 8, (size_t)nq * k * 4);
+        return CSS_OK;
+    }
+    CSS_HIP_TRY(hipMemcpyAsync(D_host, d_out, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
     CSS_HIP_TRY(hipMemcpyAsync(I_host, ix->out_i, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ix->stream));
     CSS_HIP_TRY(hipStreamSynchronize(ix->stream));
     return CSS_OK;

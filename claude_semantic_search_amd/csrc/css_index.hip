@@ -235,6 +235,19 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ s
 // a time; a block's lists are merged into one global list per query under an agent-scope lock (release /
 // acquire fences around plain loads and stores, MI355X_MICROARCH.md "Valid forms"); the lists were reset by
 // the kernel that flagged the query; the block that finishes last turns them into D / I rows.
+// (rows are read once per sweep: non-temporal, like the shadow-row sweeps -- css_knn_coarse.h, cz_row_load; CSS_SCAN_NT=0 builds for A/B runs)
+#ifndef CSS_SCAN_NT
+#define CSS_SCAN_NT 1
+#endif
+__device__ __forceinline__ float4 scan_row_load(const float4* p) {
+#if CSS_SCAN_NT
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 template <int NQ, int TT, int METRIC, bool FIX = false>
 __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict__ xb, const float* __restrict__ qpad,
                                                     int64_t ntotal, int T_rt, int k, int64_t groups_per_block,
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
         if constexpr (TT > 0) {
             float4 xv[TT > 0 ? TT : 1];
 #pragma unroll
-            for (int t = 0; t < TT; ++t) xv[t] = xr[t * 16];
+            for (int t = 0; t < TT; ++t) xv[t] = scan_row_load(xr + t * 16);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
 #pragma unroll
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_small(const float4* __restrict_
             }
         } else {
             for (int t = 0; t < T; ++t) {
-                const float4 x = xr[t * 16];
+                const float4 x = scan_row_load(xr + t * 16);
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     const float4 q = qs4[j * (T * 16) + t * 16 + sub];

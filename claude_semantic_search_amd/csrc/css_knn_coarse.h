@@ -809,6 +809,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         ur[kd] = (int)(u0 % gm1);
         tbase[kd] = (size_t)tile0 * CZ_T * (size_t)ROWB;
     }
+#ifndef C8_ROW_AUX
+#define C8_ROW_AUX 0   // cache policy of the row-tile LDS-DMA (2 = non-temporal: measured)
+#endif
 #define C8_ISSUE(KIND_, DB_)                                                                                  \
     {                                                                                                         \
         const bool isA_ = (KIND_) == C8_A0 || (KIND_) == C8_A1;                                               \
@@ -816,9 +819,11 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
         const unsigned o0_ = lofs[KIND_] + (unsigned)it_kt[KIND_] * 128u;                                     \
         const unsigned o1_ = (o0_ + row8) ^ 64u;                                                              \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o0_),        \
-            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_]), 16, 0, 0); \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_]), 16, 0, \
+            ((KIND_) == C8_A0 || (KIND_) == C8_A1) ? 0 : C8_ROW_AUX);                                          \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_ + o1_),        \
-            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_] + 1024), 16, 0, 0); \
+            (__attribute__((address_space(3))) void*)(smem + ((DB_) * 4 + (KIND_)) * C8_HT + dsto[KIND_] + 1024), 16, 0, \
+            ((KIND_) == C8_A0 || (KIND_) == C8_A1) ? 0 : C8_ROW_AUX);                                          \
         if (++it_kt[KIND_] == KT) {                                                                           \
             it_kt[KIND_] = 0;                                                                                 \
             if (!isA_ && it_tile[KIND_] + 1 < my_ntiles) {                                                    \

@@ -1551,6 +1551,7 @@ struct KnnEnv {
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
+    int sweep_maxq = -1;    // CSS_KNN_SWEEP_MAXQ=n: searches of up to n (0..4) queries take the sweep cascade (A/B runs); -1 = by size
     int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
     int fs_blocks = 0;      // CSS_KNN_FS_BLOCKS=n: at most n blocks of k_sweep_cascade per CU (A/B runs); 0 = what fits
     int mfma_shape = 16;  // CSS_KNN_MFMA=32: 32x32x16 MFMA in k_scan_coarse (A/B runs)
@@ -1579,6 +1580,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_FS_SPINS")) e.fs_spins = std::max(0, atoi(m));
+        if (const char* m = getenv("CSS_KNN_SWEEP_MAXQ")) e.sweep_maxq = std::min(4, std::max(0, atoi(m)));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_DBG")) e.dbg = atoi(m);
@@ -2509,7 +2511,13 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     // 1..4 queries through the sweep cascade: its init launch prepares the query rows as well (one launch less in front
     // of a 1.4 ms search).  Which shadow rows a search reads is decided once (the per-index int8 feedback counts searches).
-    const bool sweep_wanted = ix->ntotal > 0 && nq <= 4 && k <= CSS_KERNEL_MAX_K && env.batch == 0 &&
+    // 3 or 4 queries are VALU-bound in the sweep (10 M rows: 2.65 ms at k = 10) and sooner through the int8 MFMA scan of
+    // batches where that applies (1.98 ms; 1 M rows: sweep 0.34 vs scan 0.39 ms; k = 100 goes through the bf16 scan, 3.2 ms
+    // against the sweep's 2.8-2.9); two queries always sweep (1.36 vs 1.93 ms).  tools/knn_fewq_probe.py, one session.
+    const bool i8_scan_ok = ix->x8 != nullptr && ix->metric == CSS_METRIC_IP && ix->dpad % 256 == 0 && ix->dpad <= 1024 &&
+                            env.batch_i8 != 0 && env.loop8 && env.mfma_shape == 16;
+    const int sweep_max = env.sweep_maxq >= 0 ? env.sweep_maxq : ((k <= 32 && ix->ntotal >= 3000000 && i8_scan_ok) ? 2 : 4);
+    const bool sweep_wanted = ix->ntotal > 0 && nq <= sweep_max && k <= CSS_KERNEL_MAX_K && env.batch == 0 &&
                               (ix->xh != nullptr || ix->x8 != nullptr) &&
                               (ix->search_mode == CSS_SEARCH_COARSE ||
                                (ix->search_mode == CSS_SEARCH_AUTO && (k > 32 || ix->ntotal >= 100000)));
@@ -2549,7 +2557,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     // An index with int8 rows only takes the candidate path where the int8 rows are chosen; otherwise it goes on like an
     // index without shadow rows (bf16 scratch ranges for batches, the exact kernels for a few queries).
     if (want_candidates && (ix->xh != nullptr || ix->x8 != nullptr)) {
-        const bool sweep = nq <= 4;  // measured at 10M x 768: sweep 2.7 / 2.7 / 3.1 ms for 1 / 2 / 4 queries, MFMA scan 3.8 ms for 5..32
+        const bool sweep = nq <= sweep_max;
         const bool use_i8 = ix->x8 != nullptr && (sweep ? sweep_i8 : batch_i8_wanted(ix, k, ix->ntotal, nq));
         if (use_i8 || ix->xh != nullptr) {
             if (sweep) return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true, use_i8, true, q_dev, normalize_q);

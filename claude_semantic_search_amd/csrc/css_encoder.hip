@@ -49,6 +49,7 @@ struct LayerW {
 // the defaults are the product configuration.
 struct EncEnv {
     int resid = 2;        // CSS_ENC_RESID: residual stream storage in bf16 mode (see forward_typed)
+    int gemm4w = 0;       // CSS_GEMM_4W: bit mask of the folded GEMMs that run on k_gemm4w (1 QKV, 2 O, 4 FFN1, 8 FFN2)
     int dbg = 0;          // CSS_GEMM_DBG bit0: skip epilogue, bit1: skip MFMA, bit2: skip loads (timing experiments)
     bool big_tiles = true;   // CSS_GEMM_TILE=128: the 128x128 tiles everywhere
     bool mfma16 = true;      // CSS_GEMM_MFMA=32: 32x32x16 MFMA kernel (k_gemm) instead of k_gemm16
@@ -61,6 +62,7 @@ struct EncEnv {
         if (const char* t = getenv("CSS_GEMM_TILE")) big_tiles = atoi(t) != 128;
         if (const char* t = getenv("CSS_GEMM_DBG")) dbg = atoi(t);
         if (const char* t = getenv("CSS_ENC_RESID")) resid = atoi(t);
+        if (const char* t = getenv("CSS_GEMM_4W")) gemm4w = atoi(t);
         if (const char* t = getenv("CSS_GEMM_MFMA")) mfma16 = atoi(t) != 32;
         if (const char* t = getenv("CSS_GEMM_LOOP")) loop8 = std::string(t) != "old";
         if (const char* t = getenv("CSS_ENC_FUSE_LN")) fuse_ln = atoi(t) != 0;
@@ -358,6 +360,26 @@ int launch_gemm8p(const void* A, const void* W, const float* bias, void* C, int 
     CSS_LAUNCH_CHECK();
     return CSS_OK;
 }
+// k_gemm4w launch (the LayerNorm-folded GEMMs on four 128 x 128 waves per block; CSS_GEMM_4W=0 keeps k_gemm8p)
+template <int EPI, int TAG = 0>
+int launch_gemm4w(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int qscale_cols,
+                  float qscale, const G8Side& side, int num_cus, hipStream_t st, const char* prof) {
+    CSS_REQUIRE(N % 256 == 0 && K % 64 == 0 && K >= 256 && (size_t)M * K * 2 < ((size_t)1 << 32), "gemm4w: bad shape %d x %d x %d", M, N, K);
+    auto kern = k_gemm4w<EPI, TAG>;
+    constexpr size_t lds = 2 * 65536;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int rc_ = css::ensure_dynamic_lds((const void*)kern, lds, dev_);
+    if (rc_ != CSS_OK) return rc_;
+    const int ntiles = (N / 256) * ((M + 255) / 256);
+    int grid = std::min(ntiles, side.grid > 0 ? std::min(side.grid, num_cus) : num_cus);
+    grid = std::max(8, grid / 8 * 8);
+    ProfScope ps(prof, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K,
+                       qscale_cols, qscale, side);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
 // CSS_GEMM_TILE=128 selects the 128x128 variant (A/B experiments)
 
 template <typename TIn, int EPI>
@@ -512,8 +534,11 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.stats_out = e->stats[1];
         side.cgroup = enc_env().cg_qkv;
         side.grid = enc_env().grid_qkv;
-        if ((rc = launch_gemm8p<EPI_AFF_QKV, true>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
-                                             side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
+        const int g4 = enc_env().gemm4w;
+        if ((rc = (g4 & 1) ? launch_gemm4w<EPI_AFF_QKV>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
+                                                          side, e->num_cus, st, "enc_gemm_qkv")
+                           : launch_gemm8p<EPI_AFF_QKV, true>(pre[0], L.wqkv_f, L.dqkv, e->qkv, T, 3 * H, H, H, 0.125f * 1.44269504088896341f,
+                                                                side, e->num_cus, st, "enc_gemm_qkv")) != CSS_OK)
             return rc;
         {
             ProfScope ps("enc_attention", st);
@@ -528,21 +553,24 @@ int forward_folded_bf16(css_encoder* e, const int32_t* ids, const int32_t* cu, i
         side.cvec = g_in;
         side.cgroup = enc_env().cg_o;
         side.grid = enc_env().grid_o;
-        if ((rc = launch_gemm8p<EPI_RES, true, 1>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
+        if ((rc = (g4 & 2) ? launch_gemm4w<EPI_RES, 1>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")
+                           : launch_gemm8p<EPI_RES, true, 1>(e->ctx, L.wo_p, L.bo_f, pre[1], T, H, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_o")) != CSS_OK)
             return rc;
         // x1 = LN1(pre[1]) -> ffn = gelu(x1 W1^T + b1); zeroes stats[0]
         side.stats_in = e->stats[1];
         side.stats_out = e->stats[0];
         side.cgroup = enc_env().cg_ffn1;
         side.grid = enc_env().grid_ffn1;
-        if ((rc = launch_gemm8p<EPI_AFF_GELU, true>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
+        if ((rc = (g4 & 4) ? launch_gemm4w<EPI_AFF_GELU>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")
+                           : launch_gemm8p<EPI_AFF_GELU, true>(pre[1], L.w1_f, L.d1, e->ffn, T, F, H, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn1")) != CSS_OK)
             return rc;
         // pre[0] = ffn W2^T + (b2 + beta1) + gamma1 (pre[1] - mu) rs; stats[0] += row sums
         side.pprev = pre[1];
         side.cvec = L.ln1g;
         side.cgroup = enc_env().cg_ffn2;
         side.grid = enc_env().grid_ffn2;
-        if ((rc = launch_gemm8p<EPI_RES, true>(e->ffn, L.w2_p, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
+        if ((rc = (g4 & 8) ? launch_gemm4w<EPI_RES>(e->ffn, L.w2_p, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")
+                           : launch_gemm8p<EPI_RES, true>(e->ffn, L.w2_p, L.b2_f, pre[0], T, H, F, 0, 1.0f, side, e->num_cus, st, "enc_gemm_ffn2")) != CSS_OK)
             return rc;
         g_in = L.ln2g;
         b_in = L.ln2b;

@@ -1382,6 +1382,396 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 #undef G8_SET_SRC
 }
 
+// ---------------------------------------------------------------- k_gemm4w: FOUR waves of 128 x 128, one per SIMD
+// The LayerNorm-folded GEMMs (blocked A, blocked weights, blocked output: EPI_AFF_* / EPI_RES) on the loop that
+// tools/gemm_lab.hip v5 measured against the 8-phase loop of k_gemm8p (round 4): per K step a 4-wave block reads 128 KB of
+// fragments from LDS instead of 192 KB (two waves x 128 x 64 per SIMD re-read what one 128 x 128 wave reads once), and
+// the loop -- bound by LDS traffic + LDS-DMA issue, profiles/r04_gemm_loop_ablations.txt -- ran 1.37-1.40 PFLOP/s against
+// 1.09-1.15 on the FFN1 shape with the epilogue switched off.  What it takes:
+//  * the 256 accumulator registers of a wave live in AGPRs: every MFMA is inline asm with a "+a" accumulator operand
+//    (hipcc left to itself keeps part of them in VGPRs and spills: gemm_lab v3, 500 TFLOP/s);
+//  * a hand-placed stream (every asm statement clobbers "memory", so the written order is the issued order): the 64
+//    MFMAs of a half K step carry the 16 fragment reads of the NEXT half step, one per 4 MFMAs (two A sets, ONE B set: B
+//    fragment n is dead behind the 8 MFMAs that use it), the second half also the 16 LDS-DMA pieces of the stage after
+//    next (saddr-form inline asm: scalar base per piece, lane * 16 as the only vector offset);
+//  * ONE block barrier per K step, in its middle: behind it stage g + 1 has landed for every wave and every wave has
+//    finished reading stage g - 1's slot;
+//  * tiles outside, K steps inside (accumulators loop-carried through the inner loop only).
+// Side data, statistics and epilogue arithmetic are k_gemm8p's (same fixed-order sums: bit-identical outputs).
+template <int EPI, int TAG = 0>
+__global__ __launch_bounds__(256) void k_gemm4w(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
+                                                int K, int qscale_cols, float qscale, G8Side side) {
+    static_assert(EPI == EPI_AFF_QKV || EPI == EPI_AFF_GELU || EPI == EPI_RES, "LayerNorm-folded epilogues (blocked operands and output)");
+    constexpr bool AFF = EPI == EPI_AFF_QKV || EPI == EPI_AFF_GELU;
+    constexpr bool RES = EPI == EPI_RES;
+    constexpr bool DO_GELU = EPI == EPI_AFF_GELU;
+    constexpr bool DO_QSCALE = EPI == EPI_AFF_QKV;
+    constexpr int NW = 4, BM = 256, BN = 256, STAGE = 65536, A_BYTES = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A: 16 blocks x 2 KiB | B: 16 blocks x 2 KiB]
+    __shared__ __attribute__((aligned(16))) float sbias[2][6][BN];   // side data of two tiles (parity): k_gemm8p's layout
+    __shared__ __attribute__((aligned(16))) float spart[NW][64 * 4];  // RES: a wave's row sums, slot = lane
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lq = lane & 15, lg = lane >> 4;
+
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
+    const int KT = K / 64;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+    const int cg = (side.cgroup > 0 && ntn % side.cgroup == 0 && xfirst % ntn == 0 && xcount % ntn == 0) ? side.cgroup : 0;
+    const int cg_per = cg ? (xcount / ntn) * cg : 1;
+#define G4_TILE(IDX_) g8_tile((IDX_), xfirst, ntn, cg, cg_per)
+
+    // ---- LDS-DMA: piece I (0..7: the two 1-KiB halves of this wave's four A blocks, 8..15: of its four B blocks) of stage
+    // gi into slot gi & 1.  A block = 16 rows x 64 columns of the blocked operand, 2 KiB contiguous at
+    // (row >> 4) * rowstride + (k >> 6) * 2048: the scalar base carries tile, block row and K step, the lanes only lane * 16.
+    const size_t rsK = preblk_rowstride(K);
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int it_tile = 0, it_kt = 0, gi = 0;
+    const char* kA;   // this wave's first A block of stage gi
+    const char* kB;
+    unsigned lds_dst;
+    auto set_stage = [&]() {
+        const int tile_ = G4_TILE(jx + it_tile * per_x);
+        const int r0_ = (tile_ / ntn) * BM, c0_ = (tile_ % ntn) * BN;
+        kA = reinterpret_cast<const char*>(A) + (size_t)((r0_ >> 4) + 4 * wave) * rsK + (size_t)it_kt * 2048;
+        kB = reinterpret_cast<const char*>(W) + (size_t)((c0_ >> 4) + 4 * wave) * rsK + (size_t)it_kt * 2048;
+        lds_dst = lds0 + (gi & 1) * STAGE + wave * 8192;
+    };
+// (s_mov, not s_add, inside the asm: an s_add would clobber SCC between an s_add_u32 / s_addc_u32 pair of the compiler's own
+// address arithmetic, which it is free to schedule around the statement -- found as wrong high address halves)
+#define G4_DMA(SBASE_, IMM_)                                                                                  \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(SBASE_), "s"(lds_dst + (IMM_)) : "memory")
+#define G4_PIECE(I_)                                                                                          \
+    switch (I_) {                                                                                             \
+        case 0: G4_DMA(kA, 0); break;                                                                         \
+        case 1: G4_DMA(kA + 1024, 1024); break;                                                               \
+        case 2: G4_DMA(kA + rsK, 2048); break;                                                                \
+        case 3: G4_DMA(kA + rsK + 1024, 3072); break;                                                         \
+        case 4: G4_DMA(kA + 2 * rsK, 4096); break;                                                            \
+        case 5: G4_DMA(kA + 2 * rsK + 1024, 5120); break;                                                     \
+        case 6: G4_DMA(kA + 3 * rsK, 6144); break;                                                            \
+        case 7: G4_DMA(kA + 3 * rsK + 1024, 7168); break;                                                     \
+        case 8: G4_DMA(kB, 32768); break;                                                                     \
+        case 9: G4_DMA(kB + 1024, 33792); break;                                                              \
+        case 10: G4_DMA(kB + rsK, 34816); break;                                                              \
+        case 11: G4_DMA(kB + rsK + 1024, 35840); break;                                                       \
+        case 12: G4_DMA(kB + 2 * rsK, 36864); break;                                                          \
+        case 13: G4_DMA(kB + 2 * rsK + 1024, 37888); break;                                                   \
+        case 14: G4_DMA(kB + 3 * rsK, 38912); break;                                                          \
+        default: G4_DMA(kB + 3 * rsK + 1024, 39936); break;                                                   \
+    }
+    // (stages beyond the last one repeat a K step of the last tile into a slot nobody reads any more: no branches in the stream)
+#define G4_STAGE_DONE()                                                                                       \
+    {                                                                                                         \
+        ++gi;                                                                                                 \
+        if (++it_kt == KT) {                                                                                  \
+            it_kt = 0;                                                                                        \
+            if (it_tile + 1 < my_ntiles) ++it_tile;                                                           \
+        }                                                                                                     \
+        set_stage();                                                                                          \
+    }
+#define G4_ISSUE_ALL()                                                                                        \
+    G4_PIECE(0) G4_PIECE(1) G4_PIECE(2) G4_PIECE(3) G4_PIECE(4) G4_PIECE(5) G4_PIECE(6) G4_PIECE(7)          \
+    G4_PIECE(8) G4_PIECE(9) G4_PIECE(10) G4_PIECE(11) G4_PIECE(12) G4_PIECE(13) G4_PIECE(14) G4_PIECE(15)    \
+    G4_STAGE_DONE()
+    // side data of tile TI_ -> sbias[TI_ & 1]: six 1-KiB pieces (0: bias / d row, 1: gamma row (RES), 2..5: the tile's 256
+    // row-statistic pairs), piece p by wave p & 3
+#define G4_SIDE_PIECE(TI_, P_)                                                                                \
+    if (!(AFF && (P_) == 1)) {                                                                                \
+        const int tile_b = G4_TILE(jx + (TI_) * per_x);                                                       \
+        const float* sp_ = (P_) == 0 ? bias + (tile_b % ntn) * BN                                             \
+                         : ((P_) == 1 ? side.cvec + (tile_b % ntn) * BN                                       \
+                                      : reinterpret_cast<const float*>(side.stats_in + (size_t)(tile_b / ntn) * BM * 2) + ((P_) - 2) * 256);  \
+        __builtin_amdgcn_global_load_lds(                                                                     \
+            (const __attribute__((address_space(1))) void*)(sp_ + 4 * lane),                                  \
+            (__attribute__((address_space(3))) void*)(&sbias[(TI_) & 1][P_][0]), 16, 0, 0);                    \
+    }
+#define G4_SIDE(TI_)                                                                                          \
+    {                                                                                                         \
+        if (wave == 0) { G4_SIDE_PIECE(TI_, 0) G4_SIDE_PIECE(TI_, 4) }                                        \
+        else if (wave == 1) { G4_SIDE_PIECE(TI_, 1) G4_SIDE_PIECE(TI_, 5) }                                   \
+        else if (wave == 2) { G4_SIDE_PIECE(TI_, 2) }                                                         \
+        else { G4_SIDE_PIECE(TI_, 3) }                                                                        \
+    }
+
+    // ---- fragments: block b of an operand at b * 2048, its half c at + 1024, this lane's piece at lane * 16
+    unsigned fa_base[2], fb_base[2];   // [0]: the slot being multiplied, [1]: the other one; swapped after every K step
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        fa_base[sl] = lds0 + sl * STAGE + wr * 16384 + lane * 16;
+        fb_base[sl] = lds0 + sl * STAGE + A_BYTES + wc * 16384 + lane * 16;
+    }
+    v4f acc[8][8];
+    v4f fa[2][8], fb[8];
+#define G4_MFMA(ACC_, BF_, AF_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(BF_), "v"(AF_) : "memory")
+#define G4_READ(DST_, BASE_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:" #OFF_ : "=v"(DST_) : "v"(BASE_) : "memory")
+    // fragment IDX_ (block) of half C_ from base BASE_
+#define G4_READ_SW(DST_, BASE_, IDX_, C_)                                                                     \
+    if ((C_) == 0) {                                                                                          \
+        switch (IDX_) {                                                                                       \
+            case 0: G4_READ(DST_, BASE_, 0); break;                                                           \
+            case 1: G4_READ(DST_, BASE_, 2048); break;                                                        \
+            case 2: G4_READ(DST_, BASE_, 4096); break;                                                        \
+            case 3: G4_READ(DST_, BASE_, 6144); break;                                                        \
+            case 4: G4_READ(DST_, BASE_, 8192); break;                                                        \
+            case 5: G4_READ(DST_, BASE_, 10240); break;                                                       \
+            case 6: G4_READ(DST_, BASE_, 12288); break;                                                       \
+            default: G4_READ(DST_, BASE_, 14336); break;                                                      \
+        }                                                                                                     \
+    } else {                                                                                                  \
+        switch (IDX_) {                                                                                       \
+            case 0: G4_READ(DST_, BASE_, 1024); break;                                                        \
+            case 1: G4_READ(DST_, BASE_, 3072); break;                                                        \
+            case 2: G4_READ(DST_, BASE_, 5120); break;                                                        \
+            case 3: G4_READ(DST_, BASE_, 7168); break;                                                        \
+            case 4: G4_READ(DST_, BASE_, 9216); break;                                                        \
+            case 5: G4_READ(DST_, BASE_, 11264); break;                                                       \
+            case 6: G4_READ(DST_, BASE_, 13312); break;                                                       \
+            default: G4_READ(DST_, BASE_, 15360); break;                                                      \
+        }                                                                                                     \
+    }
+    // side action J_ of a block that multiplies half C_; the next half is half 1 - C_ of slot SL_ (0: current, 1: other).
+    // 0..7: next A fragments; 8..14: next B fragments 0..6 (their MFMAs are done); B fragment 7 follows the block
+#define G4_FRAG(SL_, C_, J_)                                                                                  \
+    if ((J_) < 8) { G4_READ_SW(fa[1 - (C_)][(J_) & 7], fa_base[SL_], (J_) & 7, 1 - (C_)) }                     \
+    else if ((J_) < 15) { G4_READ_SW(fb[((J_) - 8) & 7], fb_base[SL_], ((J_) - 8) & 7, 1 - (C_)) }
+#define G4_FRAG_LAST(SL_, C_) G4_READ_SW(fb[7], fb_base[SL_], 7, 1 - (C_))
+#define G4_QUAD(C_, J_)                                                                                       \
+    G4_MFMA(acc[4 * ((J_) % 2) + 0][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 0]);                     \
+    G4_MFMA(acc[4 * ((J_) % 2) + 1][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 1]);                     \
+    G4_MFMA(acc[4 * ((J_) % 2) + 2][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 2]);                     \
+    G4_MFMA(acc[4 * ((J_) % 2) + 3][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 3]);
+    // accumulators := bias row of parity PAR_ (AFF: zeros; the d row is applied in the epilogue)
+#define G4_ACC_FROM_BIAS(PAR_)                                                                                \
+    {                                                                                                         \
+        _Pragma("unroll") for (int n = 0; n < 8; ++n) {                                                       \
+            v4f bv_ = v4f{0.f, 0.f, 0.f, 0.f};                                                                \
+            if constexpr (!AFF) bv_ = *reinterpret_cast<const v4f*>(&sbias[PAR_][0][wc * 128 + 16 * n + 4 * lg]); \
+            _Pragma("unroll") for (int m = 0; m < 8; ++m) acc[m][n] = bv_;                                    \
+        }                                                                                                     \
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   /* (accumulator writes -> MFMAs inside asm: no hazard pass sees them) */ \
+    }
+    // EPI_RES: statistics of the PREVIOUS tile (partials of the wave row's two waves in spart since that tile's epilogue)
+    // -> one fixed-order sum per row, then fixed-point integer atomics.  Wave wc handles slots 32 wc .. 32 wc + 31
+    // (slot s = rows s and 64 + s of the wave row's 128-row block).
+    int flush_row0 = 0;
+#define G4_STATS_FLUSH()                                                                                      \
+    if constexpr (RES) {                                                                                      \
+        if (lane < 32) {                                                                                      \
+            const int sl_ = 32 * wc + lane;                                                                   \
+            const v4f q0_ = *reinterpret_cast<const v4f*>(&spart[2 * wr][sl_ * 4]);                            \
+            const v4f q1_ = *reinterpret_cast<const v4f*>(&spart[2 * wr + 1][sl_ * 4]);                        \
+            const v4f t_ = q0_ + q1_;                                                                         \
+            unsigned long long* so_ = reinterpret_cast<unsigned long long*>(side.stats_out) + (size_t)(flush_row0 + sl_) * 2; \
+            atomicAdd(so_, (unsigned long long)__float2ll_rn(t_[0] * kStatScale1));                           \
+            atomicAdd(so_ + 1, (unsigned long long)__float2ll_rn(t_[1] * kStatScale2));                       \
+            atomicAdd(so_ + 128, (unsigned long long)__float2ll_rn(t_[2] * kStatScale1));                     \
+            atomicAdd(so_ + 129, (unsigned long long)__float2ll_rn(t_[3] * kStatScale2));                     \
+        }                                                                                                     \
+    }
+
+    // ---- prologue: side data of tile 0, stages 0 and 1 on their way; stage 0 landed for everybody; its half 0 read
+    set_stage();
+    G4_SIDE(0)
+    G4_ISSUE_ALL()
+    G4_ISSUE_ALL()
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        G4_READ_SW(fa[0][j], fa_base[0], j, 0)
+        G4_READ_SW(fb[j], fb_base[0], j, 0)
+    }
+    G4_ACC_FROM_BIAS(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    for (int ct_tile = 0; ct_tile < my_ntiles; ++ct_tile) {
+#pragma unroll 1
+        for (int kt = 0; kt < KT; ++kt) {
+            // ---- block (g, 0): MFMAs on A set 0, the half-1 fragments of this stage behind them
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // (B fragment 7 was read behind the previous block, 14 reads ago, and is multiplied from here on)
+                if (j == 14) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+                G4_QUAD(0, j)
+                G4_FRAG(0, 0, j)
+            }
+            G4_FRAG_LAST(0, 0)
+            // ---- middle of the step
+            // (vmcnt(0) also behind an epilogue: its stores may complete before the older LDS-DMA pieces -- loads and stores are
+            // not ordered against each other -- so a count that lets "the 32 stores" stay outstanding proves nothing)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt == 0 && ct_tile + 1 < my_ntiles) G4_SIDE(ct_tile + 1)
+            if ((AFF || RES) && kt == 1) {   // raw (sum, sum^2) pairs -> (rs, mu rs) in place: 64 rows per wave
+                float* sp_ = &sbias[ct_tile & 1][2][(wave * 64 + lane) * 4];
+                const v4u32 raw_ = *reinterpret_cast<const v4u32*>(sp_);
+                float rs_, mrs_;
+                row_stats_decode(raw_, side.inv_h, side.eps, rs_, mrs_);
+                sp_[0] = rs_;
+                sp_[1] = mrs_;
+            }
+            if (RES && kt == 2 && ct_tile > 0) G4_STATS_FLUSH()
+            // ---- block (g, 1): MFMAs on A set 1, the half-0 fragments of stage g + 1 behind them, the DMA of stage g + 2
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                G4_QUAD(1, j)
+                G4_FRAG(1, 1, j)
+                G4_PIECE(j)
+            }
+            G4_FRAG_LAST(1, 1)
+            G4_STAGE_DONE()
+            asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");   // everything but B fragment 7 (used last) is there
+            {
+                const unsigned ta = fa_base[0], tb = fb_base[0];
+                fa_base[0] = fa_base[1];
+                fa_base[1] = ta;
+                fb_base[0] = fb_base[1];
+                fb_base[1] = tb;
+            }
+        }
+        // ---- epilogue of output tile ct_tile: k_gemm8p's arithmetic on the wave's two 64-column strips
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the last MFMAs inside asm -> accumulator reads: no hazard pass sees them)
+        {
+            const int tile = G4_TILE(jx + ct_tile * per_x);
+            const int par = ct_tile & 1;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const size_t blk_m = preblk_rowstride(N);
+            float keep[4] = {0.f, 0.f, 0.f, 0.f};   // row sums this lane reports: rows lq + 16 (lg + 4 j), (sum, sum^2)
+            if constexpr (AFF) {
+                // statistics the next EPI_RES GEMM adds into: zero this tile's rows (first tile column, wave column 0)
+                if (tile % ntn == 0 && wc == 0) {
+                    v4u* zp = reinterpret_cast<v4u*>(side.stats_out + (size_t)((tile / ntn) * BM + wr * 128) * 2);
+                    zp[lane] = v4u{0u, 0u, 0u, 0u};
+                    zp[lane + 64] = v4u{0u, 0u, 0u, 0u};
+                }
+            }
+            const float* rsp = &sbias[par][2][(wr * 128 + lq) * 4];   // (rs, mu rs) of row block m at + 64 m floats
+#ifndef G4_DBG
+#define G4_DBG 0   // -DG4_DBG=1: timing build without the epilogue's arithmetic and stores (results invalid)
+#endif
+#pragma unroll
+            for (int h = 0; h < (G4_DBG & 1 ? 0 : 2); ++h) {
+                const int w64 = 2 * wc + h;   // the 64-column strip of the tile (k_gemm8p's wave column)
+                const int col0 = (tile % ntn) * BN + w64 * 64;
+                float sc[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) sc[n] = (DO_QSCALE && col0 + 16 * n < qscale_cols) ? qscale : 1.0f;
+                v4f dj[4], gj[4];
+                if constexpr (AFF) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) dj[n] = *reinterpret_cast<const v4f*>(&sbias[par][0][w64 * 64 + 16 * n + 4 * lg]) * sc[n];
+                }
+                const size_t blk_o = (size_t)(((tile / ntn) * BM + wr * 128) >> 4) * blk_m + (size_t)((tile % ntn) * 4 + w64) * 2048 + lane * 16;
+                v4u pv[16];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) gj[n] = *reinterpret_cast<const v4f*>(&sbias[par][1][w64 * 64 + 16 * n + 4 * lg]);
+                    const char* pb = reinterpret_cast<const char*>(side.pprev) + blk_o;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        pv[2 * m] = *reinterpret_cast<const v4u*>(pb + m * blk_m);
+                        pv[2 * m + 1] = *reinterpret_cast<const v4u*>(pb + m * blk_m + 1024);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    uint2 pk[4];
+                    v4f s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
+                    const v2f st = *reinterpret_cast<const v2f*>(rsp + 64 * m);
+                    const float rs_ = st[0], mrs_ = st[1];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        v4f v = acc[m][4 * h + n];
+                        if constexpr (AFF) {
+                            const float rsn = rs_ * sc[n];
+                            v = __builtin_elementwise_fma(v, v4f{rsn, rsn, rsn, rsn}, dj[n]);
+                        }
+                        if constexpr (RES) {
+                            // acc holds branch + bias + beta; residual = gamma (p rs - mu rs) + beta
+                            const unsigned pwx = pv[2 * m + (n >> 1)][2 * (n & 1)], pwy = pv[2 * m + (n >> 1)][2 * (n & 1) + 1];
+                            v4f pf;
+                            pf[0] = __uint_as_float(pwx << 16);
+                            pf[1] = __uint_as_float(pwx & 0xFFFF0000u);
+                            pf[2] = __uint_as_float(pwy << 16);
+                            pf[3] = __uint_as_float(pwy & 0xFFFF0000u);
+                            const v4f u = __builtin_elementwise_fma(pf, v4f{rs_, rs_, rs_, rs_}, v4f{-mrs_, -mrs_, -mrs_, -mrs_});
+                            v = __builtin_elementwise_fma(gj[n], u, v);
+                            s1v += v;
+                            s2v = __builtin_elementwise_fma(v, v, s2v);
+                        }
+                        if constexpr (DO_GELU) v = gelu_poly4(v);
+                        pk[n].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        pk[n].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    }
+                    if constexpr (RES) {
+                        // row sums over this strip's 64 columns: 4 values per lane, then the 4 lanes lg = 0..3 of the row
+                        float r1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), r2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
+                        {
+                            const auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+                            const auto a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2), __float_as_uint(r2), false, false);
+                            r1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                            r2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                            const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+                            const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r2), __float_as_uint(r2), false, false);
+                            r1 = __uint_as_float(b1[0]) + __uint_as_float(b1[1]);
+                            r2 = __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
+                        }
+                        if (lg == (m & 3)) {
+                            keep[2 * (m >> 2)] += r1;       // (strip 0 then strip 1: k_gemm8p adds its four strips in that order too)
+                            keep[2 * (m >> 2) + 1] += r2;
+                        }
+                    }
+                    char* cb_ = reinterpret_cast<char*>(Cout) + blk_o + m * blk_m;
+                    if constexpr (RES) {   // (a pre tensor is the A operand of the very next GEMM: plain stores, see k_gemm8p)
+                        *reinterpret_cast<v4u*>(cb_) = v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+                        *reinterpret_cast<v4u*>(cb_ + 1024) = v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y};
+                    } else {
+                        __builtin_nontemporal_store(v4u{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, reinterpret_cast<v4u*>(cb_));
+                        __builtin_nontemporal_store(v4u{pk[2].x, pk[2].y, pk[3].x, pk[3].y}, reinterpret_cast<v4u*>(cb_ + 1024));
+                    }
+                }
+            }
+            if constexpr (RES) {
+                *reinterpret_cast<v4f*>(&spart[wave][lane * 4]) = v4f{keep[0], keep[1], keep[2], keep[3]};
+                flush_row0 = __builtin_amdgcn_readfirstlane((tile / ntn) * BM + wr * 128);
+            }
+            G4_ACC_FROM_BIAS((ct_tile + 1) & 1)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the surplus DMA pieces and fragment reads)
+    if constexpr (RES) {   // statistics of the block's last tile
+        __builtin_amdgcn_s_barrier();
+        G4_STATS_FLUSH()
+    }
+#undef G4_TILE
+#undef G4_DMA
+#undef G4_PIECE
+#undef G4_STAGE_DONE
+#undef G4_ISSUE_ALL
+#undef G4_SIDE_PIECE
+#undef G4_SIDE
+#undef G4_MFMA
+#undef G4_READ
+#undef G4_READ_SW
+#undef G4_FRAG
+#undef G4_FRAG_LAST
+#undef G4_QUAD
+#undef G4_ACC_FROM_BIAS
+#undef G4_STATS_FLUSH
+}
+
 // ---------------------------------------------------------------- skinny GEMM (M <= 64 tokens)
 // The single-query path (generate_single_embedding, src/embeddings.py:179-190) is a
 // weight-streaming problem: 85 MB of bf16 weights per forward, a few dozen tokens.  The big

@@ -720,6 +720,242 @@ __global__ __launch_bounds__(256) void k_gemm_v3(const bf16_t* __restrict__ A, c
 #undef V3_ISSUE
 }
 
+// ------------------------------------------------------------------------------------------------ v5
+// Round 4: v3's geometry (FOUR waves of 128 x 128, one per SIMD) with what v3 lacked --
+//  * accumulators pinned to AGPRs: every MFMA is inline asm with a "+a" accumulator operand (256 AGPRs), operands in VGPRs;
+//  * a hand-placed stream: the 64 MFMAs of a half step (c = 0 / 1) carry the 16 fragment reads of the NEXT half step (into
+//    the other fragment set) one per 4 MFMAs, and the c = 1 block also the 16 LDS-DMA pieces of the stage after next;
+//  * ONE barrier per K step, in its middle: behind it stage g + 1 has landed for every wave (its reads start in block
+//    (g, 1)) and every wave has finished reading stage g - 1's slot (the DMA of stage g + 2 into it starts in block (g, 1)).
+// Every asm statement clobbers "memory", so asm and DMA builtins keep their written order; the compiler only allocates.
+#define V5_MFMA(ACC_, BF_, AF_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(BF_), "v"(AF_) : "memory")
+#define V5_READ(DST_, BASE_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:" #OFF_ : "=v"(DST_) : "v"(BASE_) : "memory")
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_gemm_v5(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                 const float* __restrict__ bias, bf16_t* __restrict__ Cout, int M, int N,
+                                                 int K, int dbg = 0) {
+    constexpr int NW = 4, WN = 2, TM = 8, TN = 8, BM = 256, BN = 256, RB = 128;
+    constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB;
+    constexpr int E = 4 * TM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float sbias[BN];
+    constexpr int EPI_ROW = 272;
+    __shared__ __attribute__((aligned(16))) char sepi[NW][16 * EPI_ROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lq = lane & 15, lg = lane >> 4;
+    float4 bias_regs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xfirst = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcount = q + (xcd < r ? 1 : 0);
+    const int my_ntiles = jx < xcount ? (xcount - jx + per_x - 1) / per_x : 0;
+    const int KT = K / 64;
+    const int total = my_ntiles * KT;
+    if (total == 0) return;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    // LDS-DMA pieces as inline asm (saddr form: 64-bit scalar base = operand + K-step, 32-bit per-lane offset), so that they
+    // stay where the stream puts them: piece I (0..7: rows of A, 8..15: rows of W) of stage gi goes to slot gi & 1.
+    // voff[I]: byte offset of this lane's 16 bytes of piece I inside the operand at K step 0 (all < 2^32), per tile.
+    unsigned voffA = 0, voffB = 0;
+    const size_t step32 = (size_t)32 * K * 2;
+    const unsigned lds_dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+    auto set_src = [&](int tile_idx) {
+        const int tile = xfirst + jx + tile_idx * per_x;
+        const int r0 = (tile / ntn) * BM, c0 = (tile % ntn) * BN;
+        const int trow = wave * 8 + prow;
+        const unsigned sw = (unsigned)((pchunk ^ ((trow >> 1) & 7)) << 4);
+        voffA = (unsigned)(r0 + trow) * (unsigned)K * 2u + sw;   // (rows beyond M: the buffer's slack rows)
+        voffB = (unsigned)(c0 + trow) * (unsigned)K * 2u + sw;
+    };
+    int it_tile = 0, it_kt = 0, gi = 0;   // DMA side: next stage to issue
+    const char* kA = reinterpret_cast<const char*>(A);   // operand + K step of stage gi (uniform)
+    const char* kB = reinterpret_cast<const char*>(W);
+    unsigned lds_dst = lds_dst0;                          // slot of stage gi (uniform)
+// (s_mov, not s_add: an s_add inside the asm would clobber SCC between an s_add_u32 / s_addc_u32 pair of the compiler's)
+#define V5_DMA(VOFF_, SBASE_, IMM_)                                                                          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF_), "s"(SBASE_), "s"(lds_dst + (IMM_)) : "memory")
+#define V5_PIECE(I_)                                                                                         \
+    switch (I_) {                                                                                            \
+        case 0: V5_DMA(voffA, kA, 0); break;                                                                 \
+        case 1: V5_DMA(voffA, kA + step32, 4096); break;                                                     \
+        case 2: V5_DMA(voffA, kA + 2 * step32, 8192); break;                                                 \
+        case 3: V5_DMA(voffA, kA + 3 * step32, 12288); break;                                                \
+        case 4: V5_DMA(voffA, kA + 4 * step32, 16384); break;                                                \
+        case 5: V5_DMA(voffA, kA + 5 * step32, 20480); break;                                                \
+        case 6: V5_DMA(voffA, kA + 6 * step32, 24576); break;                                                \
+        case 7: V5_DMA(voffA, kA + 7 * step32, 28672); break;                                                \
+        case 8: V5_DMA(voffB, kB, 32768); break;                                                             \
+        case 9: V5_DMA(voffB, kB + step32, 36864); break;                                                    \
+        case 10: V5_DMA(voffB, kB + 2 * step32, 40960); break;                                               \
+        case 11: V5_DMA(voffB, kB + 3 * step32, 45056); break;                                               \
+        case 12: V5_DMA(voffB, kB + 4 * step32, 49152); break;                                               \
+        case 13: V5_DMA(voffB, kB + 5 * step32, 53248); break;                                               \
+        case 14: V5_DMA(voffB, kB + 6 * step32, 57344); break;                                               \
+        default: V5_DMA(voffB, kB + 7 * step32, 61440); break;                                               \
+    }
+    /* (stages beyond the last one repeat a K step of the last tile into a slot nobody reads any more: no branches in the stream) */
+#define V5_STAGE_DONE()                                                                                      \
+    {                                                                                                        \
+        ++gi;                                                                                                \
+        lds_dst = lds_dst0 + (gi & 1) * STAGE;                                                               \
+        if (++it_kt == KT) {                                                                                 \
+            it_kt = 0;                                                                                       \
+            if (++it_tile < my_ntiles) set_src(it_tile);                                                     \
+        }                                                                                                    \
+        kA = reinterpret_cast<const char*>(A) + (size_t)it_kt * RB;                                          \
+        kB = reinterpret_cast<const char*>(W) + (size_t)it_kt * RB;                                          \
+    }
+#define V5_ISSUE_ALL()                                                                                       \
+    V5_PIECE(0) V5_PIECE(1) V5_PIECE(2) V5_PIECE(3) V5_PIECE(4) V5_PIECE(5) V5_PIECE(6) V5_PIECE(7)         \
+    V5_PIECE(8) V5_PIECE(9) V5_PIECE(10) V5_PIECE(11) V5_PIECE(12) V5_PIECE(13) V5_PIECE(14) V5_PIECE(15)   \
+    V5_STAGE_DONE()
+    // fragment bases (LDS byte addresses): [slot][c] for A and B; fragment m / n at + m * 2048 (B: + A_BYTES)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int aoff = swz_byte(wr * 128 + lq, lg), boff = swz_byte(wc * 128 + lq, lg);
+    // [0]: the slot of the stage being multiplied, [1]: the other slot; swapped after every K step
+    unsigned ab[2][2], bb[2][2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ab[sl][c] = lds0 + sl * STAGE + (aoff ^ (c * 64));
+            bb[sl][c] = lds0 + sl * STAGE + A_BYTES + (boff ^ (c * 64));
+        }
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+    // fragments: two sets of A (set c feeds half step c), ONE set of B: B fragment n is dead behind the 8 MFMAs that use
+    // it and is reloaded for the next half step right there (256 VGPRs hold no second B set next to the DMA addressing)
+    v4f fa[2][TM], fb[TN];
+    // side action J_ of a block that multiplies half C_ (next half: slot SL_, half 1 - C_): J_ = 2 n, 2 n + 1 follow the
+    // MFMAs of B fragment n.  0..7: next A fragments, two per group; 8..14: next B fragments 0..6 (their groups are done);
+    // 15: nothing -- B fragment 7 follows the block (V5_FRAG_LAST) and is needed last in the next one
+#define V5_FRAG(SL_, C_, J_)                                                                                 \
+    if ((J_) < 8) { V5_READ_SW(fa[1 - (C_)][(J_) & 7], ab[SL_][1 - (C_)], (J_) & 7) }                         \
+    else if ((J_) < 15) { V5_READ_SW(fb[(J_) - 8], bb[SL_][1 - (C_)], (J_) - 8) }
+#define V5_FRAG_LAST(SL_, C_) V5_READ_SW(fb[7], bb[SL_][1 - (C_)], 7)
+#define V5_READ_SW(DST_, BASE_, IDX_)                                                                        \
+    switch (IDX_) {                                                                                          \
+        case 0: V5_READ(DST_, BASE_, 0); break;                                                              \
+        case 1: V5_READ(DST_, BASE_, 2048); break;                                                           \
+        case 2: V5_READ(DST_, BASE_, 4096); break;                                                           \
+        case 3: V5_READ(DST_, BASE_, 6144); break;                                                           \
+        case 4: V5_READ(DST_, BASE_, 8192); break;                                                           \
+        case 5: V5_READ(DST_, BASE_, 10240); break;                                                          \
+        case 6: V5_READ(DST_, BASE_, 12288); break;                                                          \
+        default: V5_READ(DST_, BASE_, 14336); break;                                                         \
+    }
+    // 4 MFMAs of half step C_ (B fragment J_ / 2 against A fragments 4 (J_ % 2) .. + 3), then the J_-th side action
+#define V5_QUAD(C_, J_)                                                                                      \
+    V5_MFMA(acc[4 * ((J_) % 2) + 0][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 0]);                    \
+    V5_MFMA(acc[4 * ((J_) % 2) + 1][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 1]);                    \
+    V5_MFMA(acc[4 * ((J_) % 2) + 2][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 2]);                    \
+    V5_MFMA(acc[4 * ((J_) % 2) + 3][(J_) / 2], fb[(J_) / 2], fa[C_][4 * ((J_) % 2) + 3]);
+
+    // prologue: stages 0 and 1 on their way, stage 0 landed for everybody, its c = 0 fragments read
+    set_src(0);
+    V5_ISSUE_ALL()
+    V5_ISSUE_ALL()
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // half 0 of stage 0: A set 0 and the B fragments
+        V5_READ_SW(fa[0][j], ab[0][0], j)
+        V5_READ_SW(fb[j], bb[0][0], j)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // tiles outside, K steps inside: the accumulators are loop-carried through the inner loop only and zeroed in straight-line
+    // code between two tiles (one flat loop with the epilogue under a condition made the allocator spill accumulator tiles)
+    for (int ct_tile = 0; ct_tile < my_ntiles; ++ct_tile) {
+#pragma unroll 1
+        for (int kt = 0; kt < KT; ++kt) {
+            // ---- block (g, 0): MFMAs on A set 0, the c = 1 fragments of this stage behind them
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // (B fragment 7 was read behind the previous block, 14 reads ago, and is multiplied from here on)
+                if (j == 14) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+                V5_QUAD(0, j)
+                V5_FRAG(0, 0, j)
+            }
+            V5_FRAG_LAST(0, 0)
+            // ---- middle of the step: stage g + 1 has landed (this wave's pieces; everybody's behind the barrier)
+            if (wave == 0 && kt == 2) *reinterpret_cast<float4*>(&sbias[4 * lane]) = bias_regs;
+            if (ct_tile > 0 && kt == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(E) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave == 0 && kt == 1) {
+                const int tile_b = xfirst + jx + ct_tile * per_x;
+                bias_regs = *reinterpret_cast<const float4*>(bias + (tile_b % ntn) * BN + 4 * lane);
+            }
+            // ---- block (g, 1): MFMAs on A set 1, the c = 0 fragments of stage g + 1 behind them, the DMA of stage g + 2
+            // (behind the last stage the reads fetch fragments nobody multiplies)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                V5_QUAD(1, j)
+                V5_FRAG(1, 1, j)
+                V5_PIECE(j)
+            }
+            V5_FRAG_LAST(1, 1)
+            V5_STAGE_DONE()
+            asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");   // everything but B fragment 7 (used last) is there
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {   // the other slot becomes the current one
+                const unsigned ta = ab[0][c], tb = bb[0][c];
+                ab[0][c] = ab[1][c];
+                ab[1][c] = ta;
+                bb[0][c] = bb[1][c];
+                bb[1][c] = tb;
+            }
+        }
+        {
+            const int tile = xfirst + jx + ct_tile * per_x;
+            const int col0 = (tile % ntn) * BN + wc * 128;
+            float4 bv[TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bv[n] = *reinterpret_cast<const float4*>(&sbias[wc * 128 + 16 * n + 4 * lg]);
+            if (!(dbg & 1))
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                char* mine = sepi[wave];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(acc[m][n][0] + bv[n].x) | ((unsigned)f2bf(acc[m][n][1] + bv[n].y) << 16);
+                    pk.y = (unsigned)f2bf(acc[m][n][2] + bv[n].z) | ((unsigned)f2bf(acc[m][n][3] + bv[n].w) << 16);
+                    *reinterpret_cast<uint2*>(mine + lq * EPI_ROW + (16 * n + 4 * lg) * 2) = pk;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = 4 * t + (lane >> 4);
+                    const uint4 o = *reinterpret_cast<const uint4*>(mine + rr * EPI_ROW + (lane & 15) * 16);
+                    const size_t gidx = (size_t)((tile / ntn) * BM + wr * 128 + 16 * m + rr) * N + col0 + (lane & 15) * 8;
+                    *reinterpret_cast<uint4*>(Cout + gidx) = o;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = v4f{0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (accumulator writes -> the MFMAs inside asm: no hazard pass sees them)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the surplus DMA pieces and fragment reads)
+#undef V5_PIECE
+#undef V5_STAGE_DONE
+#undef V5_ISSUE_ALL
+#undef V5_FRAG
+#undef V5_FRAG_LAST
+#undef V5_READ_SW
+#undef V5_QUAD
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static inline float bf2f_host(bf16_t h) {
     uint32_t u = (uint32_t)h << 16;
@@ -783,8 +1019,10 @@ int main(int argc, char** argv) {
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v1<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)k_gemm_v5<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&](int v) {
-        if (v == 3) hipLaunchKernelGGL(k_gemm_v3<0>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        if (v == 5) hipLaunchKernelGGL(k_gemm_v5<0>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
+        else if (v == 3) hipLaunchKernelGGL(k_gemm_v3<0>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else if (v == 4) hipLaunchKernelGGL(k_gemm_v3<1>, dim3(grid), dim3(256), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else if (v == 0) hipLaunchKernelGGL(k_gemm_v0<0>, dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
         else if (v == 1) hipLaunchKernelGGL((k_gemm_v1<0, false, 3>), dim3(grid), dim3(512), lds, 0, dA, dW, db, dC, M, N, K, dbg);
@@ -792,7 +1030,7 @@ int main(int argc, char** argv) {
     };
     // ---- correctness: sampled elements against an fp64 host reference
     std::vector<bf16_t> hC((size_t)M * N);
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
         if (!(mask & (1 << v))) continue;
         HIP_OK(hipMemset(dC, 0xFF, Mpad * N * 2));
         launch(v);
@@ -829,10 +1067,10 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0));
     HIP_OK(hipEventCreate(&e1));
-    double best[5] = {1e30, 1e30, 1e30, 1e30, 1e30}, sum[5] = {0, 0, 0, 0, 0};
+    double best[6] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30}, sum[6] = {0, 0, 0, 0, 0, 0};
     const int rounds = 5;
     for (int r = 0; r < rounds; ++r)
-        for (int v = 0; v < 5; ++v) {
+        for (int v = 0; v < 6; ++v) {
             if (!(mask & (1 << v))) continue;
             for (int i = 0; i < 3; ++i) launch(v);
             HIP_OK(hipEventRecord(e0, 0));
@@ -845,7 +1083,7 @@ int main(int argc, char** argv) {
             if (ms < best[v]) best[v] = ms;
             sum[v] += ms;
         }
-    for (int v = 0; v < 5; ++v)
+    for (int v = 0; v < 6; ++v)
         if (mask & (1 << v))
             printf("v%d: best %.4f ms (%.0f TFLOP/s), mean %.4f ms (%.0f TFLOP/s)\n", v, best[v], 2.0 * M * N * K / best[v] / 1e9,
                    sum[v] / rounds, 2.0 * M * N * K / (sum[v] / rounds) / 1e9);

@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                              : "v"(go_) : "memory");
                 const char* pb = reinterpret_cast<const char*>(side.pprev) + blk_o;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < ((G8_ABL & 8) ? 0 : 8); ++m) {
 #if defined(G8_EXP) && (G8_EXP & 2)
                     pv[2 * m] = pv[2 * m + 1] = v4u{0u, 0u, 0u, 0u};
 #else
@@ -1252,8 +1252,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
 #endif
                 }
             }
+            if (G8_ABL & 8) {   // (timing build without the epilogue's arithmetic and stores: the accumulators stay live)
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(acc[m][n]));
+            }
+#pragma unroll
+            for (int m = 0; m < ((G8_ABL & 8) ? 0 : 8); ++m) {
                 uint2 pk[4];
                 v4f s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (RES) {
@@ -1295,7 +1301,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                         s2v = __builtin_elementwise_fma(v, v, s2v);
                     }
                     if constexpr (DO_GELU) {
+#if !defined(G8_EXP) || !(G8_EXP & 32)
                         v = gelu_poly4(v);
+#endif
                     } else if constexpr (DO_QSCALE && !AFF) {
                         v[0] *= sc[n]; v[1] *= sc[n]; v[2] *= sc[n]; v[3] *= sc[n];
                     }
@@ -1324,6 +1332,11 @@ __global__ __launch_bounds__(512) void k_gemm8p(const bf16_t* __restrict__ A, co
                 if constexpr (OBLK) {
                     // blocked layout: this lane's two 16-byte pieces of block m, straight from the registers
                     char* cb_ = reinterpret_cast<char*>(Cout) + blk_o + m * blk_m;
+#if defined(G8_EXP) && (G8_EXP & 64)
+                    asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]));   // (timing build: no output stores)
+                    cb_ = nullptr;
+                    if (cb_)
+#endif
                     if constexpr (RES) {
                         // a pre tensor (151 MB at 256 x 384) is the A operand of the very next GEMM: plain stores leave it in the
                         // Infinity Cache for that reader (measured in one session: 18.64 -> 18.48 ms per forward; plain stores of

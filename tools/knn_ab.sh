@@ -3,7 +3,7 @@
 # usage: tools/knn_ab.sh "ENV1=.." "ENV2=.." ...   (use "-" for the default environment)
 for e in "$@"; do
   if [ "$e" = "-" ]; then e=""; fi
-  out=$(env $e timeout -k 10 200 python3 bench.py --no-encoder --no-cpu-baseline --no-extra --steps 5 --warmup 2 2>/dev/null)
+  out=$(env $e timeout -k 10 200 python3 bench.py --no-encoder --no-cpu-baseline --no-extra --steps 5 --warmup 2 --allow-debug 2>/dev/null)
   echo "$out" | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline'] or {}

@@ -131,7 +131,7 @@ int css_index_export(const css_index* ix, int64_t row0, int64_t n, float* x_out_
  * waits for the device (one exception: the FIRST batched search of an index without shadow rows allocates that scratch
  * -- up to half of the free HBM -- and a growing workspace is reallocated; hipMalloc / hipFree synchronise the device.
  * Later searches of the same shapes allocate nothing): queries whose candidate band overflows are re-run exactly by
- * two launches that follow every cascade and return at once when there are none.
+ * one launch that follows every cascade and returns at once when there are none.
  * Rows appended by css_index_add_dev / css_index_add_synthetic on another stream are
  * ordered before the search by an event (no caller-side synchronisation needed); successive
  * asynchronous adds on different streams are chained the same way.

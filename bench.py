@@ -886,6 +886,22 @@ def _main(argv, platform_factory):
                 roofline[f"nq1_k{kq}_traffic_bytes"] = rec["traffic"]
             extra[f"nq1_k{kq}"] = rec
             nat.prof_reset()
+        if "nq1" in args.legs and hip:   # a few queries per call (2..4: the sweep cascade, or the int8 scan; 16: the int8 scan)
+            few = {}
+            for nqf in (2, 4, 16):
+                Df = torch.empty((nqf, args.k), dtype=torch.float32, device=dev)
+                If = torch.empty((nqf, args.k), dtype=torch.int64, device=dev)
+                for _ in range(3):
+                    index.search_dev(q.data_ptr(), nqf, args.k, Df.data_ptr(), If.data_ptr(), stream, normalize=True)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    index.search_dev(q.data_ptr(), nqf, args.k, Df.data_ptr(), If.data_ptr(), stream, normalize=True)
+                fence()
+                few[f"nq{nqf}_k{args.k}_latency_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+            extra["few_queries"] = few
+            if roofline is not None:
+                roofline.update(few)
 
         # ---- the reference's user-visible query: encode one query + search it (k' = 100) ----
         if world == 1 and not args.no_encoder and "e2e" in args.legs:

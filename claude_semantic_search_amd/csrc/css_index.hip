@@ -1551,6 +1551,7 @@ struct KnnEnv {
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
+    int sweep_mfma = 1;     // CSS_KNN_SWEEP_MFMA=0: 3..16 queries never take the int8-MFMA sweep (A/B runs); 2: at every index size (tests)
     int sweep_maxq = -1;    // CSS_KNN_SWEEP_MAXQ=n: searches of up to n (0..4) queries take the sweep cascade (A/B runs); -1 = by size
     int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
     int fs_blocks = 0;      // CSS_KNN_FS_BLOCKS=n: at most n blocks of k_sweep_cascade per CU (A/B runs); 0 = what fits
@@ -1580,6 +1581,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_FS_SPINS")) e.fs_spins = std::max(0, atoi(m));
+        if (const char* m = getenv("CSS_KNN_SWEEP_MFMA")) e.sweep_mfma = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_SWEEP_MAXQ")) e.sweep_maxq = std::min(4, std::max(0, atoi(m)));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
         if (const char* m = getenv("CSS_KNN_PACE")) e.pacing = m[0] == '0' ? 0 : 1;
@@ -1988,6 +1990,37 @@ int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t cou
     return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
 }
 
+// 3..16 queries, inner product, int8 rows in view: does the sweep on the int8 MFMA (k_sweep_mfma_i8) answer sooner than what
+// it replaces -- the VALU sweep (3, 4 queries) or the 256-query tiles of the batch scan?  tools/knn_fewq_probe.py, one
+// session, ms with / without, 3 .. 16 queries: 10 M rows k = 10 1.65 / 1.92-2.07, k = 100 1.83-1.85 / 2.75-3.26; 1 M rows
+// 0.32-0.33 / 0.34-0.41 and 0.46-0.48 / 0.45-0.58; 100 k rows 0.13-0.14 / 0.15-0.16 but 0.22 / 0.18-0.20 at k = 100 (a
+// select with 100 exactly scored rows behind every stage); 20 k rows 0.11-0.12 / 0.11 and 0.17-0.19 / 0.13-0.15.
+inline bool mfma_sweep_applies(const css_index* ix, int64_t nq, int k) {
+    const int mode = knn_env().sweep_mfma;
+    if (mode == 0 || ix->x8 == nullptr || ix->metric != CSS_METRIC_IP || ix->dpad > 1024 || nq < 3 || nq > 16) return false;
+    return mode == 2 || ix->ntotal >= (k <= 32 ? 50000 : 1000000);
+}
+
+// one cascade stage of the int8 MFMA sweep (3..16 queries: k_sweep_mfma_i8); the int8 queries sit in ix->qh
+int launch_sweep_mfma(css_index* ix, int nq, int64_t count, int64_t stride, int gm1, bool stage0, hipStream_t st) {
+    const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
+    const bool main_stage = stride == 1 && !stage0;
+    const signed char* q8 = reinterpret_cast<const signed char*>(ix->qh);
+#define CSS_LAUNCH_SWEEP_MFMA(KS_, MAIN_)                                                                              \
+    hipLaunchKernelGGL((k_sweep_mfma_i8<KS_, MAIN_>), dim3(grid), dim3(256), 0, st, ix->x8, ix->x8s, q8, ix->qscale, ix->cthr,  \
+                       ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, \
+                       ix->cur_mask)
+    if (ix->dpad == 768) {
+        if (main_stage) CSS_LAUNCH_SWEEP_MFMA(12, true);
+        else CSS_LAUNCH_SWEEP_MFMA(12, false);
+    } else {
+        CSS_LAUNCH_SWEEP_MFMA(0, false);
+    }
+#undef CSS_LAUNCH_SWEEP_MFMA
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+
 // the whole sweep cascade in one launch (k_sweep_cascade); sc: the schedule as tickets
 template <int NQ, int TT, bool I8>
 int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSched& sc, int* flags, const float* qnorm2,
@@ -2045,18 +2078,20 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const float* qnorm2 = ix->qnorm2 + q0;
     D_dev += (size_t)q0 * k;
     I_dev += (size_t)q0 * k;
-    const int nq_pad = sweep ? nq : (nq + CZ_T - 1) / CZ_T * CZ_T;
+    // 3..16 queries on int8 rows (inner product): the sweep on the int8 MFMA (k_sweep_mfma_i8): int8 queries too
+    const bool sweep_mfma = sweep && use_i8 && mfma_sweep_applies(ix, nq, k);
+    const int nq_pad = sweep ? (sweep_mfma ? 16 : nq) : (nq + CZ_T - 1) / CZ_T * CZ_T;
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)
     const bool i8 = use_i8;
     const float i8_rel = sqrtf((float)ix->dpad) / 254.f;
-    const float eps_rel = i8 ? (sweep ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
+    const float eps_rel = i8 ? ((sweep && !sweep_mfma) ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
                              : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
     // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B.
     // measured = the word of maxn2 that holds the rows' error: 1 = bf16 rows, 2 = int8 rows
     const int measured = env.eps_measured ? (i8 ? 2 : 1) : 0;
-    const float* qerr2 = sweep ? nullptr : (i8 ? ix->qerr2_i8 + q0 : ix->qerr2 + q0);
+    const float* qerr2 = (sweep && !sweep_mfma) ? nullptr : (i8 ? ix->qerr2_i8 + q0 : ix->qerr2 + q0);
     // the second pass over flagged queries reads the bf16 rows with bf16 queries
     const EpsSet eps_p2{0.0078125f + 0.00048828125f, ix->qerr2 + q0, env.eps_measured ? 1 : 0};
     const int l2 = ix->metric == CSS_METRIC_L2 ? 1 : 0;
@@ -2125,7 +2160,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         for (int64_t s = s0 / g; s >= 1; s /= g) sched.push_back({s, g});
         // int8 scan (band ~4 x wider): the last step of 4 is taken as two steps of 2 -- the main stage is then half of
         // the rows under the threshold of the other half (~3 x fewer appends than 3/4 of the rows under a quarter's)
-        if (i8 && !sweep && g == 4 && sched.size() >= 2 && sched.back().stride == 1 && ntiles >= 64) {
+        if (i8 && (!sweep || sweep_mfma) && g == 4 && sched.size() >= 2 && sched.back().stride == 1 && ntiles >= 64) {
             sched.back() = {2, 2};
             sched.push_back({1, 2});
         }
@@ -2134,7 +2169,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // 1..4 queries: the stages and the selects between them as ONE launch (k_sweep_cascade), quarter tiles as tickets in stage order
     // (measured, ms one launch / one per stage: 10 M rows, 1 query k = 10 1.35 / 1.41, k = 100 1.40 / 1.56, 2 queries 1.40 /
     // 1.47, 4 queries 2.68 / 2.69; 100 k rows: 0.085 / 0.095, 0.118 / 0.125, but 2 queries 0.117 / 0.111, 4: 0.186 / 0.155)
-    bool fused = sweep && env.sweep_fused && (env.sweep_fused == 2 || nq == 1 || ix->ntotal >= 1000000) &&
+    bool fused = sweep && !sweep_mfma && env.sweep_fused && (env.sweep_fused == 2 || nq == 1 || ix->ntotal >= 1000000) &&
                  (int)sched.size() <= CZ_FS_MAXST && ntiles < (int64_t)1 << 28;
     FsSched fsched{};
     if (fused) {
@@ -2171,13 +2206,22 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
             CSS_LAUNCH_CHECK();
         }
         const int npace = use_pace ? kPaceGroups * kPaceStages : 0;
-        const int ninit = std::max(std::max(std::max(nq_pad, npace), f2), fused ? CZ_FS_KEYWORDS : 0);
+        const int ninit = std::max(std::max(std::max(std::max(nq_pad, npace), f2), fused ? CZ_FS_KEYWORDS : 0),
+                                   q_raw != nullptr ? nq * 64 : 0);   // (query prep: one wave per query)
         hipLaunchKernelGGL(k_coarse_init, dim3((ninit + 255) / 256), dim3(256), 0, st, ix->cthr, ix->cand_n, flags,
                            nflag, nq, nq_pad, (int)(n0 * CZ_T), use_pace ? ix->cpace : (int*)nullptr, npace,
                            pass2 ? ix->cand_n2 : (int*)nullptr, pass2 ? ix->thr2 : (float*)nullptr, nflagB, f2,
                            fused ? ix->fs_state : (int*)nullptr, q_raw, ix->qpad + (size_t)q0 * ix->dpad, ix->qnorm2 + q0,
                            ix->qerr2 + q0, ix->dim, ix->dpad, normalize_q);
         CSS_LAUNCH_CHECK();
+        if (sweep_mfma) {   // int8 query rows (16, zero padded), their scales and error norms -- behind the init launch, which may have prepared qpad
+            if ((rc = grow(&ix->qh, &ix->qh_cap, (size_t)nq_pad * ix->dpad)) != CSS_OK) return rc;
+            if ((rc = grow(&ix->qscale, &ix->qscale_cap, (size_t)nq_pad)) != CSS_OK) return rc;
+            if ((rc = grow(&ix->qerr2_i8, &ix->qerr2_i8_cap, (size_t)q0 + nq_pad)) != CSS_OK) return rc;
+            hipLaunchKernelGGL(k_rows_to_i8, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, qpad,
+                               reinterpret_cast<signed char*>(ix->qh), ix->qscale, ix->qerr2_i8 + q0, nq, nq_pad, ix->dpad);
+            CSS_LAUNCH_CHECK();
+        }
     }
     const size_t lds = (size_t)CZ_NST * CZ_STAGE;
     typedef void (*scan_fn)(const unsigned short*, const unsigned short*, const float*, float*, uint32_t*, int*, int64_t, int,
@@ -2192,7 +2236,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const bool i8b = i8 && !sweep;   // (batch_uses_i8 implies the 8-phase loop)
     // one-eps thresholds from exactly scored top-k candidates (k_coarse_select): the int8 scan, whose band is wide
     // (CSS_KNN_EXACTK=0 for A/B runs; the scores are inner products: batch_uses_i8)
-    const bool exact_k = i8b && env.exact_k && k * 2 <= CZ_EXK;
+    const bool exact_k = (i8b || sweep_mfma) && env.exact_k && k * 2 <= CZ_EXK;   // (both operands int8: the widest band)
     const scan_fn f_stage0 = i8b ? k_scan_coarse8<true, false, false, CZ_CAP, true>
                                  : (loop8 ? k_scan_coarse8<true, false>
                                           : (m16 ? k_scan_coarse<true, false, false, 16> : k_scan_coarse<true, false>));
@@ -2234,7 +2278,10 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         const bool stage0 = si == 0;
         const int64_t W = (ntiles + s - 1) / s;
         const int64_t count = stage0 ? W : (W - 1) - (W - 1) / gr;
-        if (count > 0 && sweep) {
+        if (count > 0 && sweep_mfma) {
+            ProfScope ps(s == 1 && !stage0 ? "knn_sweep_mfma_main" : "knn_sweep_mfma_stage", st);
+            if ((rc = launch_sweep_mfma(ix, nq, count, s, std::max(1, gr - 1), stage0, st)) != CSS_OK) return rc;
+        } else if (count > 0 && sweep) {
             ProfScope ps(s == 1 && !stage0 ? "knn_sweep_coarse_main" : "knn_sweep_coarse_stage", st);
             if (nq <= 1) rc = launch_sweep_coarse_nq<1>(ix, qpad, nq, count, s, gr - 1, stage0, st, i8);
             else if (nq <= 2) rc = launch_sweep_coarse_nq<2>(ix, qpad, nq, count, s, gr - 1, stage0, st, i8);
@@ -2511,18 +2558,19 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     // 1..4 queries through the sweep cascade: its init launch prepares the query rows as well (one launch less in front
     // of a 1.4 ms search).  Which shadow rows a search reads is decided once (the per-index int8 feedback counts searches).
-    // 3 or 4 queries are VALU-bound in the sweep (10 M rows: 2.65 ms at k = 10) and sooner through the int8 MFMA scan of
-    // batches where that applies (1.98 ms; 1 M rows: sweep 0.34 vs scan 0.39 ms; k = 100 goes through the bf16 scan, 3.2 ms
+    // 3 or 4 queries are VALU-bound in that sweep (10 M rows: 2.65 ms at k = 10): they, and up to 16 queries, sweep on the
+    // int8 MFMA where that applies (mfma_sweep_applies); where not, 3 or 4 queries are sooner through the int8 scan of
+    // batches from 3 M rows on (1.98 ms; 1 M rows: sweep 0.34 vs scan 0.39 ms; k = 100 goes through the bf16 scan, 3.2 ms
     // against the sweep's 2.8-2.9); two queries always sweep (1.36 vs 1.93 ms).  tools/knn_fewq_probe.py, one session.
     const bool i8_scan_ok = ix->x8 != nullptr && ix->metric == CSS_METRIC_IP && ix->dpad % 256 == 0 && ix->dpad <= 1024 &&
                             env.batch_i8 != 0 && env.loop8 && env.mfma_shape == 16;
-    const int sweep_max = env.sweep_maxq >= 0 ? env.sweep_maxq : ((k <= 32 && ix->ntotal >= 3000000 && i8_scan_ok) ? 2 : 4);
-    const bool sweep_wanted = ix->ntotal > 0 && nq <= sweep_max && k <= CSS_KERNEL_MAX_K && env.batch == 0 &&
-                              (ix->xh != nullptr || ix->x8 != nullptr) &&
-                              (ix->search_mode == CSS_SEARCH_COARSE ||
-                               (ix->search_mode == CSS_SEARCH_AUTO && (k > 32 || ix->ntotal >= 100000)));
-    const bool sweep_i8 = sweep_wanted && ix->x8 != nullptr && sweep_uses_i8(ix);
-    const bool sweep_path = sweep_wanted && (sweep_i8 || ix->xh != nullptr);
+    const bool mfma_sweep_ok = mfma_sweep_applies(ix, nq, k);
+    const int sweep_max = env.sweep_maxq >= 0 ? env.sweep_maxq : ((k <= 32 && ix->ntotal >= 3000000 && i8_scan_ok) ? 2 : 4);   // VALU sweep
+    const bool sweep_base = ix->ntotal > 0 && k <= CSS_KERNEL_MAX_K && env.batch == 0 && (ix->xh != nullptr || ix->x8 != nullptr) &&
+                            (ix->search_mode == CSS_SEARCH_COARSE ||
+                             (ix->search_mode == CSS_SEARCH_AUTO && (nq > 4 || k > 32 || ix->ntotal >= 100000)));
+    const bool sweep_i8 = sweep_base && ix->x8 != nullptr && (nq <= sweep_max || mfma_sweep_ok) && sweep_uses_i8(ix);
+    const bool sweep_path = sweep_base && ((mfma_sweep_ok && sweep_i8) || (nq <= sweep_max && (sweep_i8 || ix->xh != nullptr)));
     // query prep: same row kernel as ingest (normalise, zero pad, squared norm)
     if (!sweep_path) {
         const int64_t blocks = (nq + 3) / 4;
@@ -2557,7 +2605,7 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     // An index with int8 rows only takes the candidate path where the int8 rows are chosen; otherwise it goes on like an
     // index without shadow rows (bf16 scratch ranges for batches, the exact kernels for a few queries).
     if (want_candidates && (ix->xh != nullptr || ix->x8 != nullptr)) {
-        const bool sweep = nq <= sweep_max;
+        const bool sweep = sweep_path;
         const bool use_i8 = ix->x8 != nullptr && (sweep ? sweep_i8 : batch_i8_wanted(ix, k, ix->ntotal, nq));
         if (use_i8 || ix->xh != nullptr) {
             if (sweep) return launch_scan_coarse(ix, 0, (int)nq, k, D_dev, I_dev, st, sg, true, use_i8, true, q_dev, normalize_q);

@@ -138,10 +138,14 @@ __global__ __launch_bounds__(256) void k_rows_to_i8_wide(const float* __restrict
 constexpr int CZ_EXK = 256;
 // Band rescoring (k_rescore_parts): a band is split over at most CZ_PARTS blocks
 constexpr int CZ_PARTS = 16;
-// Spacing of the per-query candidate counters, in ints.  1 = packed: a 128-B line apart (32) was tried against the
-// returning device-scope atomics of the scan stages piling up on a few memory channels and measured no gain -- the
-// cost was in the hit loop of the tile epilogue, not in the atomics.
-constexpr int CZ_NS = 1;
+// Spacing of the per-query candidate counters, in ints: a 128-byte line each.  The batch scan, which adds once per
+// (row tile, query) with a count, measured no difference to packed counters; the int8 MFMA sweep of 3..16 queries adds
+// once per hit and lane, and with all sixteen counters on one line its appends queued up behind each other (1 M rows,
+// 16 queries, k = 100: 0.89 ms packed, 0.54 ms a line apart; 4 KB apart: the same).
+#ifndef CZ_NS_STRIDE
+#define CZ_NS_STRIDE 32
+#endif
+constexpr int CZ_NS = CZ_NS_STRIDE;
 // k_sweep_cascade (the 1..4-query cascade in one launch, below): its limits and its state words
 constexpr int CZ_FS_MAXST = 16;            // stages (growth 4: 4^15 tiles)
 constexpr int CZ_FS_RING = 16;             // pending quarter tiles per wave
@@ -1289,6 +1293,93 @@ __global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __
     }
 }
 
+// ------------------------------------------------------------------ 3..16 queries: the sweep on the int8 MFMA
+// The VALU sweep above costs one fp32 multiply-add per element and QUERY: four queries are VALU-bound (2.65 ms at
+// 10 M rows), and up to 32 queries went through the 256-query tiles of the batch scan, whose LDS-DMA ring re-fetches the
+// query tile for every row tile (1.95-2.0 ms).  Here the (up to 16) int8 queries sit in registers as the B operand
+// of v_mfma_i32_16x16x64_i8 -- lane l: query l & 15, bytes 16 (l >> 4) .. + 15 of every 64-byte K step -- and the int8
+// rows stream from HBM straight into the A operand (lane l: row l & 15 of a 16-row group, the same bytes), so the
+// sweep is HBM-bound again: a 16 x 16 score tile costs 12 loads of 16 bytes and 12 MFMAs per lane at 768 columns.
+// Result lane l: query l & 15, rows 4 (l >> 4) .. + 3 of the group; score = acc * row scale * query scale (exact int32
+// accumulation; error band: both operands int8, as in the batch scan).  One launch per cascade stage; thresholds,
+// selects, rescoring and fix-up are the candidate path's.
+template <int KS, bool MAIN>   // KS = dpad / 64 when known at compile time (768: 12), else 0 = run-time steps; MAIN names the stride-1 stage
+__global__ __launch_bounds__(256) void k_sweep_mfma_i8(const unsigned char* __restrict__ x8, const float* __restrict__ x8s,
+                                                       const signed char* __restrict__ q8, const float* __restrict__ qsc,
+                                                       const float* __restrict__ thr, float* __restrict__ cand_s,
+                                                       uint32_t* __restrict__ cand_i, int* __restrict__ cand_n, int64_t ntotal,
+                                                       int dpad, int nq, int64_t count, int64_t stride, int gm1, int stage0,
+                                                       const uint32_t* __restrict__ mask) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
+    const int ks = KS > 0 ? KS : dpad >> 6;
+    constexpr int KSMAX = KS > 0 ? KS : 16;   // (rows of at most 1024 elements carry int8 copies)
+    // this lane's query fragments: rows nq .. 15 of the int8 query block are zeros (k_rows_to_i8)
+    v4i_t qf[KSMAX];
+#pragma unroll
+    for (int t = 0; t < KSMAX; ++t)
+        qf[t] = t < ks ? *reinterpret_cast<const v4i_t*>(q8 + (size_t)lq * dpad + 64 * t + 16 * lg) : v4i_t{0, 0, 0, 0};
+    const float my_qs = lq < nq ? qsc[lq] : 0.f;
+    const float my_thr = (lq < nq && !stage0) ? thr[lq] : INFINITY;
+    for (int64_t u = blockIdx.x; u < count; u += gridDim.x) {
+        const int64_t tile = (stage0 ? u : u + u / gm1 + 1) * stride;
+        const int64_t row_base = tile * CZ_T + wave * 64;
+#pragma unroll 1
+        for (int grp = 0; grp < 4; grp += 2) {   // two 16-row groups per pass: 2 * ks loads of 16 bytes in flight per lane
+            v4i_t a0[KSMAX], a1[KSMAX];
+            const int64_t rA = row_base + 16 * grp + lq, rB = rA + 16;
+            const uint4* pa = reinterpret_cast<const uint4*>(x8 + (size_t)(rA < ntotal ? rA : ntotal - 1) * dpad) + lg;
+            const uint4* pb = reinterpret_cast<const uint4*>(x8 + (size_t)(rB < ntotal ? rB : ntotal - 1) * dpad) + lg;
+#pragma unroll
+            for (int t = 0; t < KSMAX; ++t) {
+                if (t < ks) {
+                    // (default cache policy: a 128-byte line is touched by two consecutive steps, 64 bytes each)
+                    const uint4 va = pa[4 * t], vb = pb[4 * t];
+                    a0[t] = v4i_t{(int)va.x, (int)va.y, (int)va.z, (int)va.w};
+                    a1[t] = v4i_t{(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
+                }
+            }
+            v4i_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < KSMAX; ++t) {
+                if (t < ks) {
+                    c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], qf[t], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], qf[t], c1, 0, 0, 0);
+                }
+            }
+            // lane: query lq, rows R0 .. R0 + 3 (group A) and + 16 (group B)
+            const int64_t R0 = row_base + 16 * grp + 4 * lg;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int64_t Rh = R0 + 16 * half;
+                const v4i_t c = half ? c1 : c0;
+                float xs[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[r] = x8s[Rh + r < ntotal ? Rh + r : ntotal - 1];
+                if (lq < nq) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = Rh + r;
+                        const float sc = (float)c[r] * xs[r] * my_qs;
+                        const bool ok = row < ntotal && CZ_ALLOWED(mask, row);
+                        if (stage0) {
+                            const size_t o = (size_t)lq * CZ_CAP + (size_t)u * CZ_T + (size_t)(row - tile * CZ_T);
+                            cand_s[o] = ok ? sc : -INFINITY;
+                            cand_i[o] = ok ? (uint32_t)row : kInvalidRow;
+                        } else if (sc >= my_thr && ok) {
+                            const int slot = atomicAdd(&cand_n[(size_t)lq * CZ_NS], 1);
+                            if (slot < CZ_CAP) {
+                                cand_s[(size_t)lq * CZ_CAP + slot] = sc;
+                                cand_i[(size_t)lq * CZ_CAP + slot] = (uint32_t)row;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Block-wide bitonic sort of P (power of two, <= CZ_CAP) LDS entries, best first: score desc, id asc.
 __device__ __forceinline__ void cz_bitonic(float* s, uint32_t* id, int P, int tid) {
     for (int size = 2; size <= P; size <<= 1)
@@ -1526,37 +1617,16 @@ __global__ __launch_bounds__(256) void k_coarse_select(float* __restrict__ cand_
         for (int i = tid; i < n; i += 256)
             if (s[i] >= Tc && id[i] != kInvalidRow) {
                 const int p_ = atomicAdd(&ex_n, 1);
-                if (p_ < CZ_EXK) ex_id[p_] = id[i];
+                if (p_ < CZ_EXK) {
+                    ex_id[p_] = id[i];
+                    ex_s[p_] = 0.f;   // (cz_rescore_rows looks at the score it replaces)
+                }
             }
         __syncthreads();
         const int T = min(ex_n, CZ_EXK);
-        const int lane_ = tid & 63, wave_ = tid >> 6;
-        // (a wave per row, two rows in flight per wave; 16-byte loads: ex_dpad is a multiple of 256 on this path)
-        const int nv = ex_dpad >> 2;
-        const float4* qr = reinterpret_cast<const float4*>(ex_q + (size_t)q * ex_dpad);
-        for (int r = wave_; r < T; r += 8) {
-            const int r2 = r + 4 < T ? r + 4 : r;
-            const float4* xa = reinterpret_cast<const float4*>(ex_x + (size_t)ex_id[r] * ex_dpad);
-            const float4* xb2 = reinterpret_cast<const float4*>(ex_x + (size_t)ex_id[r2] * ex_dpad);
-            float a_ = 0.f, b_ = 0.f;
-            for (int c = lane_; c < nv; c += 64) {
-                const float4 xv = xa[c], yv = xb2[c], qv = qr[c];
-                a_ = fmaf(xv.x, qv.x, a_);
-                a_ = fmaf(xv.y, qv.y, a_);
-                a_ = fmaf(xv.z, qv.z, a_);
-                a_ = fmaf(xv.w, qv.w, a_);
-                b_ = fmaf(yv.x, qv.x, b_);
-                b_ = fmaf(yv.y, qv.y, b_);
-                b_ = fmaf(yv.z, qv.z, b_);
-                b_ = fmaf(yv.w, qv.w, b_);
-            }
-            a_ = wave_allsum(a_);
-            b_ = wave_allsum(b_);
-            if (lane_ == 0) {
-                ex_s[r] = a_;
-                if (r2 != r) ex_s[r2] = b_;
-            }
-        }
+        // (the rescoring of the final select: four rows in flight per wave, the same summation order)
+        cz_rescore_rows(ex_s, ex_id, 0, T, reinterpret_cast<const float4*>(ex_q + (size_t)q * ex_dpad), ex_x, ex_dpad, 0,
+                        tid >> 6, tid & 63, -INFINITY);
         __syncthreads();
         if (T >= k && tid < T) {   // rank by counting (T <= CZ_EXK entries)
             const float mine = ex_s[tid];

@@ -678,6 +678,37 @@ def test_candidate_path_really_runs_for_both_metrics():
         ix.close()
 
 
+@pytest.mark.parametrize("nq", [3, 7, 12, 16])
+def test_three_to_sixteen_queries_sweep_on_the_int8_mfma(nq):
+    """3..16 inner-product queries on an index with int8 rows, from 50 k rows on (k <= 32; 3 and 4 queries reach the
+    candidate path from 100 k rows): the cascade stages run on the
+    int8 MFMA with the queries as the register operand (k_sweep_mfma_i8; css_index.hip: mfma_sweep_applies) -- the
+    reference's search (src/storage.py:429) returns the same ids whatever the batch size, so must this.  The timing
+    scopes show that the path under test is the one that ran; 17 queries go through the batch scan."""
+    from oracle import knn_oracle as ko
+    from claude_semantic_search_amd import _native as nat
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    n, d, k = 100_000, 768, 10
+    x = ko.normalize_rows(synth.rows(n, d, 41))
+    ix = IndexFlatIP(d)
+    ix.add(x)
+    ref = ko.FlatIndexOracle(d, 0)
+    ref.add(x)
+    for count, scope in ((nq, "knn_sweep_mfma_main"), (17, "knn_scan_coarse_main")):
+        q = synth.rows(count, d, 42 + count)
+        nat.prof_reset()
+        nat.prof_enable(True)
+        D, I = ix.search(q, k, normalize=True)
+        nat.prof_enable(False)
+        assert nat.prof_read(scope)[1] == 1, f"{count} queries did not take {scope}"
+        qr = ko.normalize_rows(q)
+        Dr, Ir = ref.search(qr, k)
+        assert_topk_matches(D, I, Dr, Ir, ref.rescore64(qr, Ir), f"nq={count} on the int8 MFMA sweep / batch scan")
+    nat.prof_reset()
+    ix.close()
+
+
 @pytest.mark.parametrize("n,nq,k", [(9000, 40, 100), (9000, 33, 128), (700, 4200, 10), (257, 513, 3)])
 def test_coarse_large_k_and_query_chunks(n, nq, k):
     _run_case(n, 768, nq, k, 0, True, seed=n + k)

@@ -48,3 +48,20 @@ def test_one_launch_cascade_that_gives_up_still_answers_exactly():
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, f"test_knn_gpu.py with waits that give up at once failed:\n{tail}\n{r.stderr[-2000:]}"
     assert " passed" in tail
+
+
+@pytest.mark.gpu
+def test_parity_suite_with_the_int8_mfma_sweep_forced():
+    """3..16 inner-product queries take the int8-MFMA sweep (k_sweep_mfma_i8) by themselves only from 50 k rows on (k <= 32;
+    above: from 1 M rows -- css_index.hip: mfma_sweep_applies); CSS_KNN_SWEEP_MFMA=2 sends every such search of the parity
+    suite through it -- tiny and ragged indexes, masks, id bases, duplicates, k = 100 -- and CSS_KNN_SWEEP_MFMA=0 keeps
+    what it replaces under the same tests."""
+    for mode in ("2", "0"):
+        env = dict(os.environ, CSS_KNN_SWEEP_MFMA=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
+                            "-p", "no:cacheprovider", "--deselect",
+                            "tests/test_knn_gpu.py::test_three_to_sixteen_queries_sweep_on_the_int8_mfma"],
+                           cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+        tail = "\n".join(r.stdout.splitlines()[-15:])
+        assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SWEEP_MFMA={mode} failed:\n{tail}\n{r.stderr[-2000:]}"
+        assert " passed" in tail

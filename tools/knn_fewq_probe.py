@@ -1,6 +1,6 @@
 """Few-query search latency, sweep cascade vs MFMA scan (development aid): python tools/knn_fewq_probe.py rows [rows ...]
 Run once per CSS_KNN_SWEEP_MAXQ setting (the switch is read once per process)."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import torch
 from claude_semantic_search_amd.flat_index import IndexFlatIP
@@ -12,8 +12,8 @@ for rows in [int(a) for a in sys.argv[1:]] or [10_000_000]:
     ix.reserve(rows)
     ix.add_synthetic(rows, seed=7)
     out = []
-    for nq in (1, 2, 3, 4, 5):
-        for k in (10, 100):
+    for nq in [int(v) for v in os.environ.get("FEWQ_NQ", "1,2,3,4,5,8,16,17").split(",")]:
+        for k in [int(v) for v in os.environ.get("FEWQ_K", "10,100").split(",")]:
             q = torch.from_numpy(synth.rows(nq, 768, 99)).cuda()
             D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
             I = torch.empty((nq, k), dtype=torch.int64, device="cuda")

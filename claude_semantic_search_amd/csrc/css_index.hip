@@ -1551,6 +1551,7 @@ struct KnnEnv {
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
+    int qreg = 1;           // CSS_KNN_QREG=0: the int8 batch scan's later stages on k_scan_coarse8 instead of k_scan_qreg_i8 (A/B runs)
     int sweep_mfma = 1;     // CSS_KNN_SWEEP_MFMA=0: 3..16 queries never take the int8-MFMA sweep (A/B runs); 2: at every index size (tests)
     int sweep_maxq = -1;    // CSS_KNN_SWEEP_MAXQ=n: searches of up to n (0..4) queries take the sweep cascade (A/B runs); -1 = by size
     int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
@@ -1581,6 +1582,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_FS_SPINS")) e.fs_spins = std::max(0, atoi(m));
+        if (const char* m = getenv("CSS_KNN_QREG")) e.qreg = m[0] == '0' ? 0 : 1;
         if (const char* m = getenv("CSS_KNN_SWEEP_MFMA")) e.sweep_mfma = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_SWEEP_MAXQ")) e.sweep_maxq = std::min(4, std::max(0, atoi(m)));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
@@ -2021,6 +2023,29 @@ int launch_sweep_mfma(css_index* ix, int nq, int64_t count, int64_t stride, int 
     return CSS_OK;
 }
 
+// one later stage of the int8 batch scan with the queries in registers (k_scan_qreg_i8): two 4-wave blocks per CU
+inline int qreg_grid(const css_index* ix) { return std::max(8, ix->num_cus * 2 / 8 * 8); }
+template <int KS>
+int launch_scan_qreg_t(css_index* ix, int nqt, int64_t count, int64_t stride, int gm1, bool main_stage, hipStream_t st) {
+    const size_t lds = qr_lds_bytes<KS>();
+    auto kern = main_stage ? k_scan_qreg_i8<KS, true> : k_scan_qreg_i8<KS, false>;
+    int rc;
+    if ((rc = css::ensure_dynamic_lds((const void*)kern, lds, ix->device)) != CSS_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3(qreg_grid(ix)), dim3(256), lds, st, (const unsigned char*)ix->x8,
+                       reinterpret_cast<const signed char*>(ix->qh), (const float*)ix->cthr, ix->cand_s, ix->cand_i, ix->cand_n,
+                       ix->ntotal, nqt, count, stride, gm1, ix->cur_mask, (const float*)ix->x8s, (const float*)ix->qscale);
+    CSS_LAUNCH_CHECK();
+    return CSS_OK;
+}
+inline bool qreg_applies(const css_index* ix, int nqt) {
+    return knn_env().qreg && (ix->dpad == 256 || ix->dpad == 512 || ix->dpad == 768) && (qreg_grid(ix) / 8) / nqt >= 1;
+}
+int launch_scan_qreg(css_index* ix, int nqt, int64_t count, int64_t stride, int gm1, bool main_stage, hipStream_t st) {
+    if (ix->dpad == 768) return launch_scan_qreg_t<12>(ix, nqt, count, stride, gm1, main_stage, st);
+    if (ix->dpad == 512) return launch_scan_qreg_t<8>(ix, nqt, count, stride, gm1, main_stage, st);
+    return launch_scan_qreg_t<4>(ix, nqt, count, stride, gm1, main_stage, st);
+}
+
 // the whole sweep cascade in one launch (k_sweep_cascade); sc: the schedule as tickets
 template <int NQ, int TT, bool I8>
 int launch_sweep_cascade_t(css_index* ix, const float* qpad, int nq, const FsSched& sc, int* flags, const float* qnorm2,
@@ -2290,14 +2315,18 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
-            // (int8 rows: no sibling pacing -- a row tile fetched by every query-tile block on its own is still only
-            // ~3.5 TB/s worst case at this scan's speed, and the coupling costs more than the HBM traffic it saves:
-            // 9.65 vs 9.02 ms per batch; the bf16 scan reads twice the bytes per row and needs it)
-            int* pace = (env.pacing && !i8b && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
-            hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, scan_rows, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
-                               ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg,
-                               (const int*)nullptr, scan_xsc, scan_qsc);
-            CSS_LAUNCH_CHECK();
+            if (i8b && !stage0 && !env.dbg && qreg_applies(ix, nqt)) {   // int8 rows, later stages: the queries stay in registers
+                if ((rc = launch_scan_qreg(ix, nqt, count, s, gr - 1, s == 1, st)) != CSS_OK) return rc;
+            } else {
+                // (int8 rows: no sibling pacing -- a row tile fetched by every query-tile block on its own is still only
+                // ~3.5 TB/s worst case at this scan's speed, and the coupling costs more than the HBM traffic it saves:
+                // 9.65 vs 9.02 ms per batch; the bf16 scan reads twice the bytes per row and needs it)
+                int* pace = (env.pacing && !i8b && grid / 8 <= kPaceGroups / 8 && stage_idx < kPaceStages) ? ix->cpace + (size_t)stage_idx * kPaceGroups : nullptr;
+                hipLaunchKernelGGL(f, dim3(grid), dim3(512), lds, st, scan_rows, ix->qh, ix->cthr, ix->cand_s, ix->cand_i,
+                                   ix->cand_n, ix->ntotal, ix->dpad, nqt, count, s, gr - 1, pace, ix->cur_mask, xn2, env.dbg,
+                                   (const int*)nullptr, scan_xsc, scan_qsc);
+                CSS_LAUNCH_CHECK();
+            }
         }
         ++stage_idx;
         if (s == 1) {

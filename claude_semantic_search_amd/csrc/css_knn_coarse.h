@@ -1001,6 +1001,245 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
 #undef CZ_TILE_OF
 }
 
+// ------------------------------------------------------------------ k_scan_qreg_i8: the int8 scan with the queries in registers
+// k_scan_coarse8 streams BOTH operands of every 256 x 256 tile through LDS: 24 fragment reads of 1 KiB per 64 MFMAs and
+// wave, ~96 of the CU's 128 B/clk at the full MFMA rate, and runs at ~45 % of the int8 peak.  Here the queries never
+// move: a wave keeps 64 of them -- all K columns, 4 KS fragments of 16 B per lane: 192 registers at K = 768 -- for its whole
+// life (the first 32 fragments in AGPRs, which v_mfma reads as its second operand directly; hipcc splits the 256
+// registers of a wave 128 / 128 at two waves per SIMD, so the rest sit in VGPRs), and only the index rows pass through
+// LDS: a ring of QR_RING groups of 16 rows (LDS-DMA, the XOR-swizzled 128-byte-chunk layout of the other scan kernels), each
+// read by the 4 waves of the block -- KS fragment reads per 4 KS MFMAs and wave, a sixth of the LDS traffic.  Two 4-wave
+// blocks per CU (a block = 256 queries x a stream of row tiles, mapped to XCDs like k_scan_coarse8); one block barrier per
+// group; no operand ever waits in a register for a compiler-inserted vmcnt(0): query loads, DMA and LDS reads of the loop
+// are inline asm.  tools/scan_lab.hip is the loop alone (5 M rows x 1024 queries: 2.75-2.85 ms = 2.8 POPS where
+// k_scan_coarse8's main stage takes 3.4 ms for 1000 queries); ring depth (3..6 groups) and groups per barrier (1, 2) measured
+// the same there -- the loop runs at the rate the chip's clock under a dense int8 MFMA load allows.
+// Stages after the first only (stage 0 keeps every score: k_scan_coarse8<true, ..>); inner product; K = 256, 512 or 768.
+// Epilogue per group: score = acc * row scale (units of the query scale, as in k_scan_coarse8) against thr / query scale; a
+// wave-wide vote per 16 queries keeps the usual case at a convert, a multiply and a compare per score; hits go through
+// the wave's LDS list and CZ_FLUSH.  (The MFMAs being asm, the hazard recogniser does not see them: explicit s_nop before
+// the first VALU read of an accumulator.)
+constexpr int QR_RING = 4;
+template <int KS>
+constexpr size_t qr_lds_bytes() { return (size_t)QR_RING * (KS / 2) * 2048; }
+template <int KS, bool MAIN>
+__global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __restrict__ x8, const signed char* __restrict__ q8,
+                                                         const float* __restrict__ thr, float* __restrict__ cand_s,
+                                                         uint32_t* __restrict__ cand_i, int* __restrict__ cand_n,
+                                                         int64_t ntotal, int nqt, int64_t count, int64_t stride, int gm1,
+                                                         const uint32_t* __restrict__ mask, const float* __restrict__ xsc,
+                                                         const float* __restrict__ qsc) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    static_assert(KS == 4 || KS == 8 || KS == 12, "K = 256, 512 or 768 int8 columns");
+    constexpr bool I8 = true;          // (CZ_FLUSH: list scores are in units of the query scale)
+    constexpr int KCAP = CZ_CAP;
+    constexpr int ROWB = 64 * KS;      // bytes per row
+    constexpr int GSLOT = (KS / 2) * 2048;   // a group in LDS: [KS / 2 chunks of 128 B][16 rows][128 B]
+    constexpr int NPW = KS / 4;        // DMA pieces (1 KiB: 8 rows x 128 B) per wave and group
+    constexpr int NA = 4 * KS < 32 ? 4 * KS : 32;   // query fragments held in AGPRs
+    (void)MAIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the ring
+    __shared__ __attribute__((aligned(16))) float sxs[2][CZ_T];   // row scales of the tile being computed / the next one
+    __shared__ float wl[4][3][CZ_WCAP];                            // per-wave hit lists: [score | row | query] (CZ_FLUSH)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, lg = lane >> 4;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int slots = per_x / nqt;
+    if (jx >= slots * nqt) return;
+    const int qtile = jx % nqt;
+    const int64_t u0 = xcd + 8 * (jx / nqt), ustep = 8 * slots;
+    const int my_ntiles = u0 < count ? (int)((count - u0 + ustep - 1) / ustep) : 0;
+    const int nsteps = my_ntiles * 16;
+    if (nsteps == 0) return;
+    const int qbase = qtile * CZ_T + wave * 64;
+
+    // resident query fragments: query qbase + 16 j + lq, bytes 64 t + 16 lg .. + 15 (asm loads: hipcc would wait for its own
+    // loads at their first use INSIDE the loop, with a vmcnt that drains the DMA ring)
+    v4i_t qf[4][KS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const signed char* src = q8 + (size_t)(qbase + 16 * j + lq) * ROWB + 64 * t + 16 * lg;
+            if (j * KS + t < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[j][t]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[j][t]) : "v"(src) : "memory");
+        }
+    float thr_q[4];   // thresholds in units of the query scale (+-inf stay; scales are > 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) thr_q[j] = thr[qbase + 16 * j + lq] / qsc[qbase + 16 * j + lq];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned sxs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sxs[0][0];
+    const unsigned wl_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&wl[wave][0][0];
+    int wcount = 0;   // entries in this wave's hit list (wave uniform)
+
+    // DMA: piece p of a group = chunk p >> 1, rows 8 (p & 1) .. + 7; this wave issues pieces NPW wave .. + NPW - 1
+    const int prow = lane >> 3, pchunk = lane & 7;
+    unsigned lofs[NPW], ldst[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = NPW * wave + i, kc = p >> 1, srow = 8 * (p & 1) + prow;
+        lofs[i] = (unsigned)srow * ROWB + (unsigned)kc * 128u + (unsigned)((pchunk ^ ((srow >> 1) & 7)) << 4);
+        ldst[i] = (unsigned)(kc * 2048 + (p & 1) * 1024);
+    }
+    const unsigned sc_lofs = (unsigned)(wave * 64 + lane) * 4u;   // scale DMA: 4 bytes per lane, this wave's 64 rows of a tile
+    // tile of ordinal u: (u + u / gm1 + 1) * stride (multiples of the growth factor belong to earlier stages); u advances by
+    // ustep per tile, quotient and remainder by gm1 are carried along
+    const int sq = (int)(ustep / gm1), sr = (int)(ustep % gm1);
+    int iu = (int)u0, iuq = (int)(u0 / gm1), iur = (int)(u0 % gm1), itile_n = 0;   // issue side
+    const char* ibase = reinterpret_cast<const char*>(x8) + (size_t)(((int64_t)iu + iuq + 1) * stride) * CZ_T * ROWB;
+    int is_step = 0;
+// (s_mov of a compiler-computed operand into m0 inside the statement: see G4_DMA in css_encoder_kernels.h)
+#define QR_DMA16(SBASE_, VOFF_, LDS_) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF_), "s"(SBASE_), "s"(LDS_) : "memory")
+#define QR_DMA4(SBASE_, VOFF_, LDS_) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(VOFF_), "s"(SBASE_), "s"(LDS_) : "memory")
+// group is_step -> ring slot is_step % QR_RING; past the end the last group once more, into a free slot (the counted
+// vmcnt below stays uniform).  A tile's row scales travel in front of its first group (one more, older, operation: the
+// counted waits only get stricter).
+#define QR_ISSUE()                                                                                                     \
+    {                                                                                                                  \
+        if (is_step < nsteps) {                                                                                        \
+            const int g_ = is_step & 15;                                                                               \
+            if (g_ == 0) {                                                                                             \
+                if (is_step > 0) {                                                                                     \
+                    iu += (int)ustep;                                                                                  \
+                    iuq += sq;                                                                                         \
+                    iur += sr;                                                                                         \
+                    if (iur >= gm1) {                                                                                  \
+                        iur -= gm1;                                                                                    \
+                        ++iuq;                                                                                         \
+                    }                                                                                                  \
+                    ++itile_n;                                                                                         \
+                }                                                                                                      \
+                const int64_t t_ = ((int64_t)iu + iuq + 1) * stride;                                                   \
+                ibase = reinterpret_cast<const char*>(x8) + (size_t)t_ * CZ_T * ROWB;                                  \
+                QR_DMA4(xsc + (size_t)t_ * CZ_T, sc_lofs, sxs_base + (unsigned)(itile_n & 1) * (CZ_T * 4u) + (unsigned)wave * 256u); \
+            } else {                                                                                                   \
+                ibase += 16 * ROWB;                                                                                    \
+            }                                                                                                          \
+        }                                                                                                              \
+        const unsigned dst_ = smem_base + (unsigned)(is_step % QR_RING) * GSLOT;                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPW; ++i_) QR_DMA16(ibase, lofs[i_], dst_ + ldst[i_]);                 \
+        ++is_step;                                                                                                     \
+    }
+#pragma unroll 1
+    for (int i = 0; i < QR_RING - 1; ++i) QR_ISSUE()
+
+    const unsigned a_o0 = smem_base + (unsigned)cz_swz(lq, lg), a_o1 = a_o0 ^ 64u;
+    int cu = (int)u0, cuq = (int)(u0 / gm1), cur_ = (int)(u0 % gm1), ctile_n = 0;   // compute side
+    int64_t cur_tile = ((int64_t)cu + cuq + 1) * stride;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        const int grp = s & 15;
+        if (grp == 0 && s > 0) {
+            cu += (int)ustep;
+            cuq += sq;
+            cur_ += sr;
+            if (cur_ >= gm1) {
+                cur_ -= gm1;
+                ++cuq;
+            }
+            ++ctile_n;
+            cur_tile = ((int64_t)cu + cuq + 1) * stride;
+        }
+        // own pieces of group s have landed when at most the NPW (QR_RING - 2) youngest DMA instructions are outstanding
+        static_assert(QR_RING == 4, "counted waits below");
+        if constexpr (NPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (NPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's pieces of group s are in LDS; everybody is done with group s - 1
+        QR_ISSUE()                      // group s + QR_RING - 1 -> the slot of group s - 1
+        const unsigned slot = (unsigned)(s % QR_RING) * GSLOT;
+        v4i_t acc[4];
+        v4i_t a[4];   // fragment reads run three K steps ahead of the MFMAs
+#define QR_LD(D_, T_) asm volatile("ds_read_b128 %0, %1" : "=v"(D_) : "v"(((T_) & 1 ? a_o1 : a_o0) + slot + (unsigned)((T_) >> 1) * 2048u) : "memory")
+#define QR_MFMA0(J_, T_)                                                                                             \
+    if ((J_) * KS + (T_) < NA) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc[J_]) : "v"(a[(T_) & 3]), "a"(qf[J_][T_])); \
+    else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc[J_]) : "v"(a[(T_) & 3]), "v"(qf[J_][T_]));
+#define QR_MFMA(J_, T_)                                                                                              \
+    if ((J_) * KS + (T_) < NA) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[J_]) : "v"(a[(T_) & 3]), "a"(qf[J_][T_])); \
+    else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[J_]) : "v"(a[(T_) & 3]), "v"(qf[J_][T_]));
+        QR_LD(a[0], 0);
+        QR_LD(a[1], 1);
+        QR_LD(a[2], 2);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            if (t + 3 < KS) {
+                QR_LD(a[(t + 3) & 3], t + 3);
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            } else if (t + 2 < KS) {
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            } else if (t + 1 < KS) {
+                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (t == 0) {
+                QR_MFMA0(0, 0) QR_MFMA0(1, 0) QR_MFMA0(2, 0) QR_MFMA0(3, 0)
+            } else {
+                QR_MFMA(0, t) QR_MFMA(1, t) QR_MFMA(2, t) QR_MFMA(3, t)
+            }
+        }
+#undef QR_LD
+#undef QR_MFMA0
+#undef QR_MFMA
+        // ---- epilogue of the group: lane (lq, lg) holds queries qbase + 16 j + lq, rows 4 lg + r
+        float4 sv4;
+        {
+            const unsigned sa_ = sxs_base + (unsigned)((ctile_n & 1) * CZ_T + grp * 16 + 4 * lg) * 4u;
+            // (the s_nop: results of the asm MFMAs are read by VALU instructions right below)
+            asm volatile("ds_read_b128 %0, %1\n\ts_nop 15\n\ts_nop 3\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv4) : "v"(sa_) : "memory");
+        }
+        const float svs[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+        float v[4][4];
+        unsigned anym = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = (float)acc[j][r] * svs[r];
+            const float mx = fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3]));
+            anym |= __ballot(mx >= thr_q[j]) != 0ull ? 1u << j : 0u;
+        }
+        if (anym != 0u) {
+            const int64_t row0 = cur_tile * CZ_T + grp * 16;
+            const bool edge = row0 + 16 > ntotal || mask != nullptr;   // wave uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (((anym >> j) & 1u) == 0u) continue;   // wave uniform
+                const unsigned qv = (unsigned)(qbase + 16 * j + lq);
+                // one pass per row position r (static register indices: a per-lane pick out of v[j][.] becomes a scratch
+                // access, whose pending load would put a vmcnt(0) -- the whole DMA ring -- in front of the loop's LDS reads)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + 4 * lg + r;
+                    bool hit = v[j][r] >= thr_q[j];
+                    if (edge) hit = hit && row < ntotal && CZ_ALLOWED(mask, row);
+                    const unsigned long long b = __ballot(hit);
+                    if (b == 0ull) continue;   // wave uniform
+                    if (wcount + 64 > CZ_WCAP) {
+                        CZ_FLUSH();
+                    }
+                    if (hit) {
+                        const unsigned sl = (unsigned)wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                        const unsigned ad = wl_base + sl * 4u;
+                        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                                     : : "v"(ad), "v"(v[j][r]), "v"((unsigned)row), "v"(qv), "n"(CZ_WCAP * 4), "n"(CZ_WCAP * 8) : "memory");
+                    }
+                    wcount += __popcll(b);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wcount > 0) CZ_FLUSH();
+#undef QR_ISSUE
+#undef QR_DMA16
+#undef QR_DMA4
+}
+
 // Row loads of the 1..4-query sweeps.  Every row is read ONCE per search, so the loads are non-temporal: the 7.7 GB of a
 // 10 M-row sweep no longer push what IS reused (the encoder's weights between two queries, the candidate buffers) out of
 // L2 / the Infinity Cache, and the sweep itself got faster -- one query, 10 M rows: cascade kernel 1.30 -> 1.24 ms

@@ -15,7 +15,7 @@ cascade on every shard -> ONE RCCL all-gather of the packed per-shard top-k (nq*
 
 The JSON line also carries:
   roofline      dominant kernel of the timed region -- the main stage of the search cascade,
-                k_scan_coarse8<false,true,..> on the int8 shadow rows (int8 MFMA peak; `frac_of_bf16_peak`
+                k_scan_qreg_i8<12,true> (k_scan_coarse8<false,true,..> under CSS_KNN_QREG=0) on the int8 shadow rows (int8 MFMA peak; `frac_of_bf16_peak`
                 beside it; the bf16 scan where the library takes that) -- measured with HIP events on the
                 launch stream inside this run (css_prof_*); `traffic` = L2-miss (fabric-side) bytes per launch
                 from the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes).
@@ -793,8 +793,11 @@ def _main(argv, platform_factory):
             flops = 2.0 * main_rows * args.dim * args.nq          # ALGORITHMIC flops (multiply-adds x 2) of that launch
             sweep_bytes = main_rows * (args.dim + 4 if scan_i8 else args.dim * 2)   # shadow rows (int8 + scale / bf16) read once
             peak_ = INT8_MFMA_PEAK_TF if scan_i8 else BF16_MFMA_PEAK_TF
+            # int8 rows of 256 / 512 / 768 columns: the stages after the first run with the queries resident in registers
+            qreg = scan_i8 and args.dim in (256, 512, 768) and os.environ.get("CSS_KNN_QREG", "1")[:1] != "0"
             roofline = {"bound": "mfma",
-                        "kernel": ("k_scan_coarse8<false,true,false,4096,true> (cascade main stage, int8 rows)" if scan_i8
+                        "kernel": (f"k_scan_qreg_i8<{args.dim // 64},true> (cascade main stage, int8 rows, queries in registers)" if qreg else
+                                   "k_scan_coarse8<false,true,false,4096,true> (cascade main stage, int8 rows)" if scan_i8
                                    else "k_scan_coarse8<false,true,false,4096,false> (cascade main stage, bf16 rows)"),
                         "achieved": flops / avg_s / 1e12, "peak": peak_, "unit": "TFLOP/s",
                         "frac": flops / avg_s / 1e12 / peak_, "traffic": None,
@@ -805,7 +808,9 @@ def _main(argv, platform_factory):
                         "frac_of_bf16_peak": flops / avg_s / 1e12 / BF16_MFMA_PEAK_TF,
                         "executed_mfma_TFLOPs": flops * (-(-args.nq // 256) * 256 / args.nq) / avg_s / 1e12}
             if scan_i8:
-                roofline["note"] = "LDS-traffic / power bound loop; CSS_KNN_SCAN=bf16 measures the bf16 scan (DESIGN.md 3.1)"
+                roofline["note"] = ("MFMA-paced loop at the clock the chip holds under it; CSS_KNN_QREG=0 measures k_scan_coarse8, "
+                                    "CSS_KNN_SCAN=bf16 the bf16 scan (DESIGN.md 3.1)") if qreg else \
+                    "LDS-traffic / power bound loop; CSS_KNN_SCAN=bf16 measures the bf16 scan (DESIGN.md 3.1)"
             if "knn_coarse_cascade" in kernels:
                 cms, cn = kernels["knn_coarse_cascade"]
                 roofline["cascade_ms"] = cms / cn           # all stages + selects + rescoring of one search
@@ -816,7 +821,8 @@ def _main(argv, platform_factory):
                         "launches": n, "avg_ms": ms / n}
         roofline["timed_scopes_ms"] = {k_: v[0] / v[1] for k_, v in kernels.items()}
         tr = None
-        main_names = ("k_scan_coarse8<false, true, false, 4096, true>",) if (dom == "knn_scan_coarse_main" and scan_i8) else \
+        main_names = (f"k_scan_qreg_i8<{args.dim // 64}, true>",) if (dom == "knn_scan_coarse_main" and scan_i8 and qreg) else \
+            ("k_scan_coarse8<false, true, false, 4096, true>",) if (dom == "knn_scan_coarse_main" and scan_i8) else \
             ("k_scan_coarse8<false, true, false, 4096, false>", "k_scan_coarse8<false, true, false, 4096>", "k_scan_coarse<false, true")
         for pref in ({"knn_scan_coarse_main": main_names}.get(dom, ("k_scan_small",))):
             tr = tr or pmc_traffic(pref, wl)

@@ -408,6 +408,15 @@ def test_mfma_batch_dims(d):
     _run_case(4000, d, 64, 10, 0, True, seed=d)
 
 
+@pytest.mark.parametrize("d", [200, 256, 512, 768])
+def test_batch_scan_row_widths_of_the_register_resident_query_kernel(d):
+    """Rows of 256 / 512 / 768 padded columns: the int8 batch scan's later stages keep the queries in registers
+    (k_scan_qreg_i8<4 | 8 | 12>; css_index.hip: qreg_applies) -- reached here when tests/test_knn_i8_forced_gpu.py re-runs
+    this file with CSS_KNN_SCAN=i8 (with and without CSS_KNN_QREG=0); in the plain run the bf16 scan answers.  300
+    queries = two query tiles, the second one ragged; 9000 rows = a ragged last row tile."""
+    _run_case(9000, d, 300, 10, 0, True, seed=300 + d)
+
+
 def test_config2_100k_768_1000_queries_top10():
     # BASELINE.json configs[1]: 100k x 768 index, 1000 queries, top-10 vs the CPU oracle
     _run_case(100_000, 768, 1000, 10, 0, True, seed=2)

@@ -13,12 +13,15 @@ ROOT = Path(__file__).resolve().parent.parent
 
 @pytest.mark.gpu
 def test_parity_suite_with_the_int8_scan_forced():
-    env = dict(os.environ, CSS_KNN_SCAN="i8")
-    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                        "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
-    tail = "\n".join(r.stdout.splitlines()[-15:])
-    assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 failed:\n{tail}\n{r.stderr[-2000:]}"
-    assert " passed" in tail
+    """... once with the later stages on k_scan_qreg_i8 (queries resident in registers: rows of 256 / 512 / 768 padded
+    columns) and once with CSS_KNN_QREG=0, which keeps every stage on k_scan_coarse8 (what other row widths use)."""
+    for qreg in ("1", "0"):
+        env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg)
+        r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
+                            "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+        tail = "\n".join(r.stdout.splitlines()[-15:])
+        assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 CSS_KNN_QREG={qreg} failed:\n{tail}\n{r.stderr[-2000:]}"
+        assert " passed" in tail
 
 
 @pytest.mark.gpu

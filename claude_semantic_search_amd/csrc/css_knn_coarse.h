@@ -1190,8 +1190,10 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
         float4 sv4;
         {
             const unsigned sa_ = sxs_base + (unsigned)((ctile_n & 1) * CZ_T + grp * 16 + 4 * lg) * 4u;
-            // (the s_nop: results of the asm MFMAs are read by VALU instructions right below)
-            asm volatile("ds_read_b128 %0, %1\n\ts_nop 15\n\ts_nop 3\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv4) : "v"(sa_) : "memory");
+            // (the s_nop: results of the asm MFMAs are read by VALU instructions below -- the accumulators pass THROUGH the
+            // statement, or the compiler is free to place their conversions in front of it: seen at K = 256 / 512)
+            asm volatile("ds_read_b128 %0, %5\n\ts_nop 15\n\ts_nop 3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(sv4), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(sa_) : "memory");
         }
         const float svs[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
         float v[4][4];

@@ -30,14 +30,18 @@
     } while (0)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int KS = 12;           // 64-byte K steps of a 768-column int8 row
+#ifndef LAB_KS
+#define LAB_KS 12
+#endif
+constexpr int KS = LAB_KS;       // 64-byte K steps of an int8 row (12: 768 columns)
+constexpr int NPW = KS / 4;      // DMA pieces per wave and group
 constexpr int ROWB = 64 * KS;    // bytes per row
 constexpr int GROUP = 16;        // rows per ring slot
 #ifndef LAB_G
 #define LAB_G 1
 #endif
 constexpr int G = LAB_G;                 // 16-row groups per ring slot = per barrier (1, 2 or 4: a divisor of a tile's 16)
-constexpr int GSLOT = GROUP * ROWB;      // 12 KiB: [6 chunks of 128 B][16 rows][128 B], XOR-swizzled 16-byte columns
+constexpr int GSLOT = GROUP * ROWB;      // 12 KiB at KS = 12: [KS / 2 chunks of 128 B][16 rows][128 B], XOR-swizzled 16-byte columns
 constexpr int SLOT = G * GSLOT;
 #ifndef LAB_RING
 #define LAB_RING 4
@@ -52,7 +56,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // src0 = 16 index rows (VGPRs, from LDS), src1 = 16 queries (resident: the first LAB_NA fragments of a wave in AGPRs, the
 // rest in VGPRs -- with two waves per SIMD hipcc splits the 256 registers of a wave 128 / 128), accumulators in VGPRs
 #ifndef LAB_NA
-#define LAB_NA 32
+#define LAB_NA (4 * LAB_KS < 32 ? 4 * LAB_KS : 32)
 #endif
 #ifdef LAB_SWAP
 #define LAB_F(J_, T_) ((3 - (J_)) * KS + (T_))
@@ -100,11 +104,11 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
 
     // DMA: a group = 12 pieces of 1 KiB (chunk kc = p >> 1 of 128 B, rows 8 (p & 1) .. + 7); wave w issues pieces 3 w .. 3 w + 2
     const int prow = lane >> 3, pchunk = lane & 7;
-    unsigned lofs[3];
-    unsigned ldst[3];
+    unsigned lofs[NPW];
+    unsigned ldst[NPW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int p = 3 * wave + i, kc = p >> 1, srow = 8 * (p & 1) + prow;
+    for (int i = 0; i < NPW; ++i) {
+        const int p = NPW * wave + i, kc = p >> 1, srow = 8 * (p & 1) + prow;
         lofs[i] = (unsigned)srow * ROWB + (unsigned)kc * 128u + (unsigned)((pchunk ^ ((srow >> 1) & 7)) << 4);
         ldst[i] = (unsigned)(kc * 2048 + (p & 1) * 1024);
     }
@@ -120,9 +124,8 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
         const char* base_ = reinterpret_cast<const char*>(x8) + ((size_t)tile_ * 256 + (size_t)(src_ & 15) * GROUP) * ROWB; \
         const unsigned dst_ = smem_base + (unsigned)(is_step % RING) * SLOT;                                           \
         _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                                             \
-            LAB_DMA(base_ + g_ * GSLOT, lofs[0], dst_ + g_ * GSLOT + ldst[0]);                                         \
-            LAB_DMA(base_ + g_ * GSLOT, lofs[1], dst_ + g_ * GSLOT + ldst[1]);                                         \
-            LAB_DMA(base_ + g_ * GSLOT, lofs[2], dst_ + g_ * GSLOT + ldst[2]);                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPW; ++i_)                                                         \
+                LAB_DMA(base_ + g_ * GSLOT, lofs[i_], dst_ + g_ * GSLOT + ldst[i_]);                                   \
         }                                                                                                              \
         ++is_step;                                                                                                     \
     }
@@ -136,15 +139,17 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
         // own pieces of group s have landed when at most 3 (RING - 2) younger DMA instructions are outstanding
-        constexpr int kWait = 3 * G * (RING - 2);
+        constexpr int kWait = NPW * G * (RING - 2);
         if constexpr (kWait == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (kWait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (kWait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if constexpr (kWait == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else if constexpr (kWait == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if constexpr (kWait == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else if constexpr (kWait == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if constexpr (kWait == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        static_assert(kWait == 0 || kWait == 3 || kWait == 6 || kWait == 9 || kWait == 12 || kWait == 18 || kWait == 24, "wait count");
+        static_assert(kWait == 0 || kWait == 2 || kWait == 4 || kWait == 3 || kWait == 6 || kWait == 9 || kWait == 12 || kWait == 18 || kWait == 24, "wait count");
         __builtin_amdgcn_s_barrier();   // everybody's pieces of group s are in LDS; everybody is done reading group s - 1
         LAB_ISSUE()                     // group s + RING - 1 -> the slot of group s - 1
 #pragma unroll 1
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
         }
 #undef LAB_LD
         // (the MFMAs are inline asm: the compiler's hazard recogniser does not pad a VALU read of their result)
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");   // (the accumulators pass through: nothing reads them earlier)
 #if LAB_EPI
         // lane: queries 16 j + lq, rows 4 lg + r of the group: score = acc * row scale against the query's (scaled) threshold
         {

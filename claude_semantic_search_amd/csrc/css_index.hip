@@ -1552,6 +1552,7 @@ struct KnnEnv {
     int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
     int qreg = 1;           // CSS_KNN_QREG=0: the int8 batch scan's later stages on k_scan_coarse8 instead of k_scan_qreg_i8 (A/B runs)
+    int qreg_min = 1024;    // CSS_KNN_QREG_MIN=<tile tasks>: stages with fewer (row tile, query tile) pairs stay on k_scan_coarse8 (two per block: measured, launch_scan_coarse)
     int sweep_mfma = 1;     // CSS_KNN_SWEEP_MFMA=0: 3..16 queries never take the int8-MFMA sweep (A/B runs); 2: at every index size (tests)
     int sweep_maxq = -1;    // CSS_KNN_SWEEP_MAXQ=n: searches of up to n (0..4) queries take the sweep cascade (A/B runs); -1 = by size
     int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
@@ -1583,6 +1584,7 @@ const KnnEnv& knn_env() {
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_FS_SPINS")) e.fs_spins = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_QREG")) e.qreg = m[0] == '0' ? 0 : 1;
+        if (const char* m = getenv("CSS_KNN_QREG_MIN")) e.qreg_min = std::max(0, atoi(m));
         if (const char* m = getenv("CSS_KNN_SWEEP_MFMA")) e.sweep_mfma = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_SWEEP_MAXQ")) e.sweep_maxq = std::min(4, std::max(0, atoi(m)));
         if (const char* m = getenv("CSS_KNN_MFMA")) e.mfma_shape = atoi(m) == 32 ? 32 : 16;
@@ -2315,7 +2317,12 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
         } else if (count > 0) {
             const scan_fn f = stage0 ? f_stage0 : (s == 1 ? f_main : f_mid);
             ProfScope ps(s == 1 && !stage0 ? "knn_scan_coarse_main" : "knn_scan_coarse_stage", st);
-            if (i8b && !stage0 && !env.dbg && qreg_applies(ix, nqt)) {   // int8 rows, later stages: the queries stay in registers
+            // int8 rows, later stages: the queries stay in registers (k_scan_qreg_i8) -- from two (row tile, query tile) pairs
+            // per block on: a block first loads its 256 queries.  ms per search, k = 10, 64 / 256 / 1000 queries, minimum
+            // 0 / 1024 / 4096 / never: 300 k rows 0.31, 0.35, 0.56 / 0.26, 0.31, 0.53 / 0.26, 0.31, 0.56 / 0.25, 0.31, 0.56;
+            // 3 M rows (1024 / 4096 / never) 0.70, 0.79, 2.25 / 0.73, 0.84, 2.28 / 0.78, 0.90, 2.56; 10 M rows 1.88, 1.99,
+            // 6.45 / 1.88, 2.01, 6.52 / 2.05, 2.27, 7.36.
+            if (i8b && !stage0 && !env.dbg && qreg_applies(ix, nqt) && count * nqt >= env.qreg_min) {
                 if ((rc = launch_scan_qreg(ix, nqt, count, s, gr - 1, s == 1, st)) != CSS_OK) return rc;
             } else {
                 // (int8 rows: no sibling pacing -- a row tile fetched by every query-tile block on its own is still only

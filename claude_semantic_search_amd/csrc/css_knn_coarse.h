@@ -1054,22 +1054,6 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
     if (nsteps == 0) return;
     const int qbase = qtile * CZ_T + wave * 64;
 
-    // resident query fragments: query qbase + 16 j + lq, bytes 64 t + 16 lg .. + 15 (asm loads: hipcc would wait for its own
-    // loads at their first use INSIDE the loop, with a vmcnt that drains the DMA ring)
-    v4i_t qf[4][KS];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            const signed char* src = q8 + (size_t)(qbase + 16 * j + lq) * ROWB + 64 * t + 16 * lg;
-            if (j * KS + t < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[j][t]) : "v"(src) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[j][t]) : "v"(src) : "memory");
-        }
-    float thr_q[4];   // thresholds in units of the query scale (+-inf stay; scales are > 0)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) thr_q[j] = thr[qbase + 16 * j + lq] / qsc[qbase + 16 * j + lq];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned sxs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sxs[0][0];
     const unsigned wl_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&wl[wave][0][0];
@@ -1127,6 +1111,23 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
     }
 #pragma unroll 1
     for (int i = 0; i < QR_RING - 1; ++i) QR_ISSUE()
+
+    // resident query fragments: query qbase + 16 j + lq, bytes 64 t + 16 lg .. + 15 (asm loads: hipcc would wait for its own
+    // loads at their first use INSIDE the loop, with a vmcnt that drains the DMA ring).  Behind the ring's first DMAs: one
+    // memory latency in front of the loop instead of two (the later stages of a 1 M-row index are a few tiles per block).
+    v4i_t qf[4][KS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const signed char* src = q8 + (size_t)(qbase + 16 * j + lq) * ROWB + 64 * t + 16 * lg;
+            if (j * KS + t < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[j][t]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[j][t]) : "v"(src) : "memory");
+        }
+    float thr_q[4];   // thresholds in units of the query scale (+-inf stay; scales are > 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) thr_q[j] = thr[qbase + 16 * j + lq] / qsc[qbase + 16 * j + lq];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const unsigned a_o0 = smem_base + (unsigned)cz_swz(lq, lg), a_o1 = a_o0 ^ 64u;
     int cu = (int)u0, cuq = (int)(u0 / gm1), cur_ = (int)(u0 % gm1), ctile_n = 0;   // compute side

@@ -1549,7 +1549,7 @@ struct KnnEnv {
     bool sweep_i8 = true;       // CSS_KNN_SWEEP=bf16: 1..4 queries sweep the bf16 shadow rows even where int8 rows exist (A/B runs)
     bool eps_measured = true;   // CSS_KNN_EPS=apriori: unit-roundoff error band instead of the measured one (cz_eps)
     int growth = 0;       // CSS_KNN_GROWTH=4|8|16: growth factor of the nested row sample (batched MFMA cascade); 0: by k
-    int growth_sweep = 4;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the 1..4-query sweep cascade
+    int growth_sweep = 0;   // CSS_KNN_GROWTH_SWEEP=4|8|16: the same for the few-query sweep cascades (0 = by shape: launch_scan_coarse)
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
     int qreg = 1;           // CSS_KNN_QREG=0: the int8 batch scan's later stages on k_scan_coarse8 instead of k_scan_qreg_i8 (A/B runs)
     int qreg_min = 1024;    // CSS_KNN_QREG_MIN=<tile tasks>: stages with fewer (row tile, query tile) pairs stay on k_scan_coarse8 (two per block: measured, launch_scan_coarse)
@@ -1578,7 +1578,7 @@ const KnnEnv& knn_env() {
         }
         if (const char* m = getenv("CSS_KNN_GROWTH_SWEEP")) {
             const int v = atoi(m);
-            e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 4;
+            e.growth_sweep = (v == 4 || v == 8 || v == 16) ? v : 0;
         }
         if (const char* m = getenv("CSS_KNN_SWEEP_FUSED")) e.sweep_fused = m[0] == '0' ? 0 : (m[0] == '2' ? 2 : 1);
         if (const char* m = getenv("CSS_KNN_FS_BLOCKS")) e.fs_blocks = std::max(0, atoi(m));
@@ -1971,7 +1971,10 @@ inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     if (e.batch_i8 == 0 || ix->metric != CSS_METRIC_IP || ix->dpad % 256 != 0 || ix->dpad > 1024 || !e.loop8 || e.mfma_shape != 16)
         return false;
     if (e.batch_i8 == 2) return true;
-    const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 4000000 && nq >= 256);
+    // (round 4, later stages on k_scan_qreg_i8, ms int8 / bf16: k = 100, 1000 queries: 4 M rows 4.1 / 6.1, 2 M 2.7 / 3.3, 1 M 2.0 /
+    // 2.0, 300 k 1.3 / 0.9; 256 queries: 2 M 1.0 / 1.4, 1 M 0.87 / 0.75.  k = 10: 1 M 1.04 / 1.57, 300 k 0.53 / 0.64 (256 queries
+    // 0.31 / 0.31), 100 k 0.35 / 0.31)
+    const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 2000000 && nq >= 256);
     if (!pays) return false;
     // (with <= 256 flagged queries the second pass is one query tile of bf16 scan -- a quarter of a 1000-query bf16 step --
     // and the int8 search still wins: 10 M rows in 20 000 clusters, 33 flagged: 12.8 ms against 13.3 on bf16 rows)
@@ -2171,7 +2174,11 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // g = 16 overflows the 4096-slot buffers (~k g candidates per stage) and lands in the exact fix-up: 10 ms.
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
     // (int8 scan: its band is ~4 x wider, growth 8 would append ~2500 rows per query in the main stage)
-    const int g = sweep ? env.growth_sweep : (env.growth ? env.growth : ((k <= 32 && !i8) ? 8 : 4));
+    // (3..16 queries on the int8 MFMA: one launch per stage, so below ~4 M rows fewer, larger stages win -- ms at growth 4 / 8,
+    // k = 10: 1 M rows 0.33 / 0.27, 100 k rows 0.13 / 0.10, 10 M rows 1.59 / 1.55-1.67; k = 100 overflows the buffers at
+    // growth 8 and 10 M rows, as the VALU sweep did)
+    const int g_sweep = env.growth_sweep ? env.growth_sweep : ((sweep_mfma && k <= 32 && ix->ntotal < 4000000) ? 8 : 4);
+    const int g = sweep ? g_sweep : (env.growth ? env.growth : ((k <= 32 && !i8) ? 8 : 4));
     struct Stage {
         int64_t stride;
         int ratio;   // stride of the previous stage / this stride (stage 0: unused)

@@ -1020,6 +1020,9 @@ __global__ __launch_bounds__(512) void k_scan_coarse8(const unsigned short* __re
 // the wave's LDS list and CZ_FLUSH.  (The MFMAs being asm, the hazard recogniser does not see them: explicit s_nop before
 // the first VALU read of an accumulator.)
 constexpr int QR_RING = 4;
+#ifndef QR_SETPRIO
+#define QR_SETPRIO 1
+#endif
 template <int KS>
 constexpr size_t qr_lds_bytes() { return (size_t)QR_RING * (KS / 2) * 2048; }
 template <int KS, bool MAIN>
@@ -1152,6 +1155,9 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
         else if constexpr (NPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everybody's pieces of group s are in LDS; everybody is done with group s - 1
+#if QR_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         QR_ISSUE()                      // group s + QR_RING - 1 -> the slot of group s - 1
         const unsigned slot = (unsigned)(s % QR_RING) * GSLOT;
         v4i_t acc[4];
@@ -1166,6 +1172,9 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
         QR_LD(a[0], 0);
         QR_LD(a[1], 1);
         QR_LD(a[2], 2);
+#if QR_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(1);   // MFMAs of this wave go in front of the partner wave's epilogue VALU work
+#endif
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
             if (t + 3 < KS) {
@@ -1187,6 +1196,9 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg_i8(const unsigned char* __
 #undef QR_LD
 #undef QR_MFMA0
 #undef QR_MFMA
+#if QR_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- epilogue of the group: lane (lq, lg) holds queries qbase + 16 j + lq, rows 4 lg + r
         float4 sv4;
         {

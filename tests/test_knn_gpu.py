@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
-def _run_case(n, d, nq, k, metric, normalize, seed=1, tie_eps=1e-6):
+def _run_case(n, d, nq, k, metric, normalize, seed=1, tie_eps=1e-6, with_next=False):
     from oracle import knn_oracle as ko
     from claude_semantic_search_amd.flat_index import IndexFlat
 
@@ -27,12 +27,16 @@ def _run_case(n, d, nq, k, metric, normalize, seed=1, tie_eps=1e-6):
     ref.add(xr)
     Dr, Ir = ref.search(qr, k)
     D64 = ref.rescore64(qr, np.where(Ir < 0, 0, Ir))
+    D64_next = None
+    if with_next and k < n:   # tens of thousands of result slots: rank k may tie with rank k + 1, which the lists do not show
+        _, I1 = ref.search(qr, k + 1)
+        D64_next = ref.rescore64(qr, I1[:, k:k + 1])[:, 0]
     # both search paths against the oracle: "exact_fp32" (every score formed in fp32 by the scan kernels: the
     # parity mode) and "auto" (the product default: bf16 candidate scan + exact fp32 rescoring where available)
     for mode in ("exact_fp32", "coarse", "auto"):
         hip.set_search_mode(mode)
         D, I = hip.search(q, k, normalize=normalize)
-        assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}", tie_eps=tie_eps)
+        assert_topk_matches(D, I, Dr, Ir, D64, f"[{mode}] n={n} d={d} nq={nq} k={k} metric={metric}", D64_next=D64_next, tie_eps=tie_eps)
     hip.close()
 
 
@@ -406,6 +410,13 @@ def test_mfma_batch_path(n, nq, k, metric):
 @pytest.mark.parametrize("d", [4, 64, 96, 128, 1024])
 def test_mfma_batch_dims(d):
     _run_case(4000, d, 64, 10, 0, True, seed=d)
+
+
+def test_sixteen_query_tiles_share_the_row_tiles_of_a_stage():
+    """4200 queries = a chunk of 4096 (16 query tiles: the most that share a row tile) and a ragged rest, on 40 000 rows:
+    under CSS_KNN_SCAN=i8 (tests/test_knn_i8_forced_gpu.py) the main stage of the first chunk has 78 x 16 (row tile, query
+    tile) pairs -- enough for k_scan_qreg_i8 by itself, four row-tile streams per XCD."""
+    _run_case(40_000, 768, 4200, 10, 0, True, seed=77, with_next=True)
 
 
 @pytest.mark.parametrize("d", [200, 256, 512, 768])

@@ -15,12 +15,12 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_parity_suite_with_the_int8_scan_forced():
     """... once with the later stages on k_scan_qreg_i8 (queries resident in registers: rows of 256 / 512 / 768 padded
     columns) and once with CSS_KNN_QREG=0, which keeps every stage on k_scan_coarse8 (what other row widths use)."""
-    for qreg in ("1", "0"):
-        env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg)
+    for qreg, qmin in (("1", "1024"), ("1", "0"), ("0", "1024")):   # (CSS_KNN_QREG_MIN=0: also the stages of a few tiles, and 16 query tiles)
+        env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg, CSS_KNN_QREG_MIN=qmin)
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
                             "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
-        assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 CSS_KNN_QREG={qreg} failed:\n{tail}\n{r.stderr[-2000:]}"
+        assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 CSS_KNN_QREG={qreg} CSS_KNN_QREG_MIN={qmin} failed:\n{tail}\n{r.stderr[-2000:]}"
         assert " passed" in tail
 
 

@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
         else if constexpr (kWait == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         static_assert(kWait == 0 || kWait == 2 || kWait == 4 || kWait == 3 || kWait == 6 || kWait == 9 || kWait == 12 || kWait == 18 || kWait == 24, "wait count");
+#ifndef LAB_PURE
         __builtin_amdgcn_s_barrier();   // everybody's pieces of group s are in LDS; everybody is done reading group s - 1
         LAB_ISSUE()                     // group s + RING - 1 -> the slot of group s - 1
+#endif
 #pragma unroll 1
       for (int g = 0; g < G; ++g) {
         const char* slot = smem + (s % RING) * SLOT + g * GSLOT;
@@ -161,16 +163,25 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
         a[0] = LAB_LD(0);
         a[1] = LAB_LD(1);
         a[2] = LAB_LD(2);
+#ifdef LAB_PURE
+        a[3] = LAB_LD(3);   // -DLAB_PURE: the MFMA stream alone (operands from these four reads; no barrier, DMA or reads in the loop): the chip's ceiling
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#ifdef LAB_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
 #ifdef LAB_NOP
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #endif
+#ifndef LAB_PURE
             if (t + 3 < KS) a[(t + 3) & 3] = LAB_LD(t + 3);
             if (t + 3 < KS) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
             else if (t + 2 < KS) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
             else if (t + 1 < KS) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             LAB_MFMA(acc[0], a[t & 3], 0, t)
             LAB_MFMA(acc[1], a[t & 3], 1, t)
             LAB_MFMA(acc[2], a[t & 3], 2, t)
@@ -178,6 +189,9 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
         }
 #undef LAB_LD
         // (the MFMAs are inline asm: the compiler's hazard recogniser does not pad a VALU read of their result)
+#ifdef LAB_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");   // (the accumulators pass through: nothing reads them earlier)
 #if LAB_EPI
         // lane: queries 16 j + lq, rows 4 lg + r of the group: score = acc * row scale against the query's (scaled) threshold

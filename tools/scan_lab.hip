@@ -9,6 +9,8 @@
 // peak.  Here a wave keeps its 64 queries (768 int8 columns: 48 fragments = 192 registers, meant for AGPRs) in
 // registers for its whole life; only the index rows go through LDS (a ring of 16-row groups, 12 KiB each, LDS-DMA), and
 // every group is read by the 4 waves of the block: 12 fragment reads per 48 MFMAs and wave.  Two 4-wave blocks per CU.
+// Variants: -DLAB_PURE (the MFMA stream alone: the chip's ceiling, 3.57 POPS), -DLAB_PRIO (s_setprio around the MFMAs),
+// -DLAB_PP (explicit ping-pong of two wave groups in one 8-wave block: 2.63-2.67 ms vs 2.76), -DLAB_KS=4|8, -DLAB_G, -DLAB_RING.
 // The lab's "epilogue" keeps a running maximum per (lane, query group) so that nothing is dead code; LAB_EPI=1 adds the
 // scale-multiply-compare work of the product's epilogue.
 #include <hip/hip_runtime.h>
@@ -229,6 +231,146 @@ __global__ __launch_bounds__(256, 2) void k_scan_qreg(const signed char* __restr
 #undef LAB_DMA
 }
 
+
+// -DLAB_PP: explicit ping-pong.  ONE block of 8 waves per CU, 512 queries; waves 0-3 (group A) and 4-7 (group B) share the
+// SIMDs pairwise and alternate between an M phase (the 4 KS MFMAs of one 16-row group) and an E phase (its epilogue and,
+// every other group, this wave group's DMA duty), B half a step behind A, one block barrier between half-steps: every SIMD
+// has exactly one wave in its M phase at any time.  Even groups are fetched by A's waves, odd ones by B's; a wave group
+// issues group j + PP_RING - 1 (A) / j + PP_RING (B) in the E phase of an odd group j and waits there for group j + 1 (A)
+// / j + 2 (B): both land one barrier before A's M phase needs them.
+#ifndef LAB_PP_RING
+#define LAB_PP_RING 6
+#endif
+constexpr int PP_RING = LAB_PP_RING;   // even
+__global__ __launch_bounds__(512, 1) void k_scan_pp(const signed char* __restrict__ x8, const signed char* __restrict__ q8,
+                                                    int* __restrict__ out_max, int64_t ntiles, int nqt) {
+    static_assert(PP_RING % 2 == 0 && KS == 12, "ring of an even number of groups; 3 pieces per issuing wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave >> 2, ws = wave & 3;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int slots = per_x / nqt;
+    if (jx >= slots * nqt) return;
+    const int qtile = jx % nqt;
+    const int64_t u0 = xcd + 8 * (jx / nqt), ustep = 8 * slots;
+    const int my_ntiles = u0 < ntiles ? (int)((ntiles - u0 + ustep - 1) / ustep) : 0;
+    const int nsteps = my_ntiles * 16;
+    if (nsteps == 0) return;
+    const int qbase = qtile * 512 + wave * 64;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    unsigned lofs[3], ldst[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = 3 * ws + i, kc = p >> 1, srow = 8 * (p & 1) + prow;
+        lofs[i] = (unsigned)srow * ROWB + (unsigned)kc * 128u + (unsigned)((pchunk ^ ((srow >> 1) & 7)) << 4);
+        ldst[i] = (unsigned)(kc * 2048 + (p & 1) * 1024);
+    }
+#define PP_DMA(SBASE_, VOFF_, LDS_) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF_), "s"(SBASE_), "s"(LDS_) : "memory")
+#define PP_ISSUE(GRP_)                                                                                                 \
+    {                                                                                                                  \
+        const int src_ = min((GRP_), nsteps - 1);   /* past the end: the last group once more, into a free slot */      \
+        const int64_t tile_ = u0 + (int64_t)(src_ >> 4) * ustep;                                                       \
+        const char* base_ = reinterpret_cast<const char*>(x8) + ((size_t)tile_ * 256 + (size_t)(src_ & 15) * GROUP) * ROWB; \
+        const unsigned dst_ = smem_base + (unsigned)((GRP_) % PP_RING) * GSLOT;                                        \
+        PP_DMA(base_, lofs[0], dst_ + ldst[0]);                                                                        \
+        PP_DMA(base_, lofs[1], dst_ + ldst[1]);                                                                        \
+        PP_DMA(base_, lofs[2], dst_ + ldst[2]);                                                                        \
+    }
+#define PP_WAIT()                                                                                                      \
+    {                                                                                                                  \
+        constexpr int kW = 3 * (PP_RING - 2) / 2;                                                                      \
+        static_assert(kW == 3 || kW == 6 || kW == 9, "wait count");                                                    \
+        if constexpr (kW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                        \
+        else if constexpr (kW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                   \
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                          \
+    }
+    // prologue: A fetches the even groups 0 .. PP_RING - 2, B the odd groups 1 .. PP_RING - 1
+#pragma unroll 1
+    for (int g = wg; g < PP_RING; g += 2) PP_ISSUE(g)
+    v4i qf[4][KS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const signed char* src = q8 + (size_t)(qbase + 16 * j + lq) * ROWB + 64 * t + 16 * lg;
+            if (LAB_F(j, t) < LAB_NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[j][t]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[j][t]) : "v"(src) : "memory");
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (everything, the prologue's groups included)
+    __builtin_amdgcn_s_barrier();                       // ... of every wave
+    const int a_o0 = swz(lq, lg), a_o1 = a_o0 ^ 64;
+    int run_max[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+#define PP_LD(SLOT_, T_) (*reinterpret_cast<const v4i*>((SLOT_) + ((T_) >> 1) * 2048 + (((T_) & 1) ? a_o1 : a_o0)))
+    v4i a[4];   // the first three fragments of a group are read in the E phase in front of its M phase
+    a[0] = PP_LD(smem, 0);
+    a[1] = PP_LD(smem, 1);
+    a[2] = PP_LD(smem, 2);
+    if (wg == 1) __builtin_amdgcn_s_barrier();   // B runs half a step behind A
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        // ---- M phase
+        const char* slot = smem + (s % PP_RING) * GSLOT;
+        v4i acc[4] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            if (t + 3 < KS) a[(t + 3) & 3] = PP_LD(slot, t + 3);
+            if (t + 3 < KS) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (t + 2 < KS) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (t + 1 < KS) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LAB_MFMA(acc[0], a[t & 3], 0, t)
+            LAB_MFMA(acc[1], a[t & 3], 1, t)
+            LAB_MFMA(acc[2], a[t & 3], 2, t)
+            LAB_MFMA(acc[3], a[t & 3], 3, t)
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- E phase (the partner group is in its M phase)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) run_max[j] = max(run_max[j], acc[j][r]);
+        if (wg == 0) {
+            if (s & 1) {
+                PP_ISSUE(s + PP_RING - 1)
+            } else {   // group s + 2 (fetched by this wave group three steps ago) has landed
+                static_assert(PP_RING == 6 || PP_RING == 8, "A's wait count");
+                if constexpr (PP_RING == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+        } else if (s & 1) {
+            PP_ISSUE(s + PP_RING)
+            PP_WAIT()   // group s + 2 has landed
+        }
+        {   // group s + 1 is in LDS and visible (its fetchers waited at least one barrier ago)
+            const char* nslot = smem + ((s + 1) % PP_RING) * GSLOT;
+            a[0] = PP_LD(nslot, 0);
+            a[1] = PP_LD(nslot, 1);
+            a[2] = PP_LD(nslot, 2);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+#undef PP_LD
+    if (wg == 0) __builtin_amdgcn_s_barrier();   // balance B's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = run_max[j];
+        m = max(m, __shfl_xor(m, 16));
+        m = max(m, __shfl_xor(m, 32));
+        if (lg == 0) atomicMax(&out_max[qbase + 16 * j + lq], m);
+    }
+#undef PP_ISSUE
+#undef PP_DMA
+#undef PP_WAIT
+}
+
 // reference: max over rows of the int32 dot product, one block per query
 __global__ void k_ref_max(const signed char* x8, const signed char* q8, int* out, int64_t nrows) {
     const int q = blockIdx.x;
@@ -257,7 +399,11 @@ int main(int argc, char** argv) {
     const int reps = argc > 3 ? atoi(argv[3]) : 10;
     const int check = argc > 4 ? atoi(argv[4]) : 0;
     const int64_t ntiles = rows / 256;
+#ifdef LAB_PP
+    const int nqt = nq / 512;
+#else
     const int nqt = nq / 256;
+#endif
     signed char *x8, *q8;
     float *xs, *thr;
     int *omax, *oref, *ohits;
@@ -280,6 +426,16 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
+#ifdef LAB_PP
+    const int grid = cus / 8 * 8;
+    const size_t lds = (size_t)PP_RING * GSLOT;
+    HIP_OK(hipFuncSetAttribute((const void*)k_scan_pp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_pp, 512, lds));
+    hipFuncAttributes fa;
+    HIP_OK(hipFuncGetAttributes(&fa, (const void*)k_scan_pp));
+#define LAB_LAUNCH() hipLaunchKernelGGL(k_scan_pp, dim3(grid), dim3(512), lds, 0, x8, q8, omax, ntiles, nqt)
+#else
     const int grid = cus / 8 * 8 * 2;
     const size_t lds = (size_t)RING * SLOT;
     HIP_OK(hipFuncSetAttribute((const void*)k_scan_qreg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -287,9 +443,11 @@ int main(int argc, char** argv) {
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_qreg, 256, lds));
     hipFuncAttributes fa;
     HIP_OK(hipFuncGetAttributes(&fa, (const void*)k_scan_qreg));
+#define LAB_LAUNCH() hipLaunchKernelGGL(k_scan_qreg, dim3(grid), dim3(256), lds, 0, x8, q8, xs, thr, omax, ohits, ntiles, nqt)
+#endif
     printf("rows=%lld nq=%d grid=%d lds=%zu occupancy=%d blocks/CU regs=%d scratch=%zu\n", (long long)rows, nq, grid, lds, occ,
            fa.numRegs, (size_t)fa.localSizeBytes);
-    hipLaunchKernelGGL(k_scan_qreg, dim3(grid), dim3(256), lds, 0, x8, q8, xs, thr, omax, ohits, ntiles, nqt);
+    LAB_LAUNCH();
     HIP_OK(hipDeviceSynchronize());
     if (check) {
         hipLaunchKernelGGL(k_ref_max, dim3(nq), dim3(256), 0, 0, x8, q8, oref, ntiles * 256);
@@ -313,7 +471,7 @@ int main(int argc, char** argv) {
     for (int round = 0; round < 3; ++round) {
         HIP_OK(hipEventRecord(e0));
         for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(k_scan_qreg, dim3(grid), dim3(256), lds, 0, x8, q8, xs, thr, omax, ohits, ntiles, nqt);
+            LAB_LAUNCH();
         HIP_OK(hipEventRecord(e1));
         HIP_OK(hipEventSynchronize(e1));
         float ms;

@@ -2115,12 +2115,18 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)
     const bool i8 = use_i8;
+    int rc_early = CSS_OK;
     const float i8_rel = sqrtf((float)ix->dpad) / 254.f;
     const float eps_rel = i8 ? ((sweep && !sweep_mfma) ? i8_rel : 2.f * i8_rel + i8_rel * i8_rel) + 0.00048828125f
                              : (sweep ? 0.00390625f + 0.00048828125f : 0.0078125f + 0.00048828125f);
     // ... tightened by the rounding errors actually measured at ingest / query prep (cz_eps); CSS_KNN_EPS=apriori for A/B.
     // measured = the word of maxn2 that holds the rows' error: 1 = bf16 rows, 2 = int8 rows
     const int measured = env.eps_measured ? (i8 ? 2 : 1) : 0;
+    // (the int8 queries' error norms: sized HERE, before the pointer below is taken -- until round 4 the buffer grew further
+    // down, so the selects of the first int8 search with more queries than any before read the freed, shorter one: zeros on
+    // a fresh device, i.e. a band without the query term; stale bytes otherwise, i.e. everything flagged -- 744 of 1000
+    // queries and 33 ms in the third index of one process, tools/seq_probe.py)
+    if (i8 && (!sweep || sweep_mfma) && (rc_early = grow(&ix->qerr2_i8, &ix->qerr2_i8_cap, (size_t)q0 + nq_pad)) != CSS_OK) return rc_early;
     const float* qerr2 = (sweep && !sweep_mfma) ? nullptr : (i8 ? ix->qerr2_i8 + q0 : ix->qerr2 + q0);
     // the second pass over flagged queries reads the bf16 rows with bf16 queries
     const EpsSet eps_p2{0.0078125f + 0.00048828125f, ix->qerr2 + q0, env.eps_measured ? 1 : 0};
@@ -2605,6 +2611,8 @@ int search_dev_enqueue(css_index* ix, const float* q_dev, int64_t nq, int k, int
     if ((rc = grow(&ix->qpad, &ix->qpad_cap, (size_t)(nq + 256) * ix->dpad)) != CSS_OK) return rc;
     if ((rc = grow(&ix->qnorm2, &ix->qnorm2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->qerr2, &ix->qerr2_cap, (size_t)nq + 256)) != CSS_OK) return rc;
+    // (int8 rows: the int8 queries' error norms of every chunk of this search -- never reallocated between two chunks)
+    if (ix->x8 != nullptr && (rc = grow(&ix->qerr2_i8, &ix->qerr2_i8_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     if ((rc = grow(&ix->gthr, &ix->gthr_cap, (size_t)nq + 256)) != CSS_OK) return rc;
     // 1..4 queries through the sweep cascade: its init launch prepares the query rows as well (one launch less in front
     // of a 1.4 ms search).  Which shadow rows a search reads is decided once (the per-index int8 feedback counts searches).

@@ -319,3 +319,32 @@ def test_rows_beyond_2_pow_26_of_one_add_are_ingested():
     D_, I_ = ix.search(q, 1, normalize=False)
     assert abs(float(D_[0, 0]) - 1.0) < 1e-5
     ix.close()
+
+
+@pytest.mark.gpu
+def test_first_search_with_more_queries_than_before_uses_fresh_query_error_norms():
+    """Until round 4 launch_scan_coarse took the pointer to the int8 queries' error norms BEFORE the buffer behind it grew:
+    the selects of the first int8 search with more queries than any before on that index read the freed, shorter buffer --
+    zeros on a fresh device (a band without the query term), stale bytes of freed indexes otherwise: in the third index
+    of one process (10 M, 3 M, 1 M rows; 256 then 1000 queries each) 744 of 1000 queries were flagged, the search took
+    33 ms and the index backed off to the bf16 rows.  Results stayed exact (the flagged queries end in the fix-up), so the
+    symptom is the flagged count: zero for every search of that sequence now."""
+    import torch
+    from claude_semantic_search_amd import synth
+    from claude_semantic_search_amd.flat_index import IndexFlatIP
+
+    st = torch.cuda.current_stream().cuda_stream
+    for rows in (10_000_000, 3_000_000, 1_000_000):
+        ix = IndexFlatIP(768)
+        ix.reserve(rows)
+        ix.add_synthetic(rows, seed=7)
+        for nq in (256, 1000):
+            q = torch.from_numpy(synth.rows(nq, 768, 99)).cuda()
+            D = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
+            I = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+            for it in range(2):
+                ix.search_dev(q.data_ptr(), nq, 10, D.data_ptr(), I.data_ptr(), st, normalize=True)
+                torch.cuda.synchronize()
+                assert ix.last_flagged() == 0, f"{rows} rows, {nq} queries, search {it}: {ix.last_flagged()} queries flagged"
+            assert (I >= 0).all() and (I < rows).all() and (D[:, :-1] >= D[:, 1:]).all()
+        ix.close()

@@ -1997,15 +1997,20 @@ int launch_sweep_coarse_nq(css_index* ix, const float* qpad, int nq, int64_t cou
     return launch_sweep_coarse_t<NQ, 0, false>(ix, qpad, nq, count, stride, gm1, stage0, st);
 }
 
-// 3..16 queries, inner product, int8 rows in view: does the sweep on the int8 MFMA (k_sweep_mfma_i8) answer sooner than what
+// 3..32 queries, inner product, int8 rows in view: does the sweep on the int8 MFMA (k_sweep_mfma_i8) answer sooner than what
 // it replaces -- the VALU sweep (3, 4 queries) or the 256-query tiles of the batch scan?  tools/knn_fewq_probe.py, one
 // session, ms with / without, 3 .. 16 queries: 10 M rows k = 10 1.65 / 1.92-2.07, k = 100 1.83-1.85 / 2.75-3.26; 1 M rows
 // 0.32-0.33 / 0.34-0.41 and 0.46-0.48 / 0.45-0.58; 100 k rows 0.13-0.14 / 0.15-0.16 but 0.22 / 0.18-0.20 at k = 100 (a
 // select with 100 exactly scored rows behind every stage); 20 k rows 0.11-0.12 / 0.11 and 0.17-0.19 / 0.13-0.15.
 inline bool mfma_sweep_applies(const css_index* ix, int64_t nq, int k) {
     const int mode = knn_env().sweep_mfma;
-    if (mode == 0 || ix->x8 == nullptr || ix->metric != CSS_METRIC_IP || ix->dpad > 1024 || nq < 3 || nq > 16) return false;
-    return mode == 2 || ix->ntotal >= (k <= 32 ? 50000 : 1000000);
+    if (mode == 0 || ix->x8 == nullptr || ix->metric != CSS_METRIC_IP || ix->dpad > 1024 || nq < 3 || nq > 32) return false;
+    if (mode == 2) return true;
+    // 17..32 queries (two fragment sets per lane), ms with / without: k = 10: 10 M rows 1.78 / 1.66 (the batch scan with the
+    // queries in registers is ahead there), 1 M rows 0.33 / 0.38, 100 k rows 0.13 / 0.155; k = 100: 10 M rows 2.0 / 3.2-3.3
+    // (the bf16 scan: fewer than 256 queries), 1 M rows 0.56-0.59 / 0.53
+    if (nq > 16) return k <= 32 ? (ix->ntotal >= 50000 && ix->ntotal < 4000000) : ix->ntotal >= 2000000;
+    return ix->ntotal >= (k <= 32 ? 50000 : 1000000);
 }
 
 // one cascade stage of the int8 MFMA sweep (3..16 queries: k_sweep_mfma_i8); the int8 queries sit in ix->qh
@@ -2013,15 +2018,24 @@ int launch_sweep_mfma(css_index* ix, int nq, int64_t count, int64_t stride, int 
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
     const bool main_stage = stride == 1 && !stage0;
     const signed char* q8 = reinterpret_cast<const signed char*>(ix->qh);
-#define CSS_LAUNCH_SWEEP_MFMA(KS_, MAIN_)                                                                              \
-    hipLaunchKernelGGL((k_sweep_mfma_i8<KS_, MAIN_>), dim3(grid), dim3(256), 0, st, ix->x8, ix->x8s, q8, ix->qscale, ix->cthr,  \
+#define CSS_LAUNCH_SWEEP_MFMA(KS_, MAIN_, NG_)                                                                         \
+    hipLaunchKernelGGL((k_sweep_mfma_i8<KS_, MAIN_, NG_>), dim3(grid), dim3(256), 0, st, ix->x8, ix->x8s, q8, ix->qscale, ix->cthr,  \
                        ix->cand_s, ix->cand_i, ix->cand_n, ix->ntotal, ix->dpad, nq, count, stride, gm1, stage0 ? 1 : 0, \
                        ix->cur_mask)
-    if (ix->dpad == 768) {
-        if (main_stage) CSS_LAUNCH_SWEEP_MFMA(12, true);
-        else CSS_LAUNCH_SWEEP_MFMA(12, false);
-    } else {
-        CSS_LAUNCH_SWEEP_MFMA(0, false);
+    if (nq <= 16) {
+        if (ix->dpad == 768) {
+            if (main_stage) CSS_LAUNCH_SWEEP_MFMA(12, true, 1);
+            else CSS_LAUNCH_SWEEP_MFMA(12, false, 1);
+        } else {
+            CSS_LAUNCH_SWEEP_MFMA(0, false, 1);
+        }
+    } else {   // 17..32 queries: two fragment sets per lane
+        if (ix->dpad == 768) {
+            if (main_stage) CSS_LAUNCH_SWEEP_MFMA(12, true, 2);
+            else CSS_LAUNCH_SWEEP_MFMA(12, false, 2);
+        } else {
+            CSS_LAUNCH_SWEEP_MFMA(0, false, 2);
+        }
     }
 #undef CSS_LAUNCH_SWEEP_MFMA
     CSS_LAUNCH_CHECK();
@@ -2110,7 +2124,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     I_dev += (size_t)q0 * k;
     // 3..16 queries on int8 rows (inner product): the sweep on the int8 MFMA (k_sweep_mfma_i8): int8 queries too
     const bool sweep_mfma = sweep && use_i8 && mfma_sweep_applies(ix, nq, k);
-    const int nq_pad = sweep ? (sweep_mfma ? 16 : nq) : (nq + CZ_T - 1) / CZ_T * CZ_T;
+    const int nq_pad = sweep ? (sweep_mfma ? (nq <= 16 ? 16 : 32) : nq) : (nq + CZ_T - 1) / CZ_T * CZ_T;
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
     // error of one coarse score relative to ||q|| max||x||: both operands bf16 (MFMA scan) or rows only (sweep)
     // int8 rows: a-priori |x^ - x| <= (s / 2) sqrt(d), s = max|x_i| / 127 <= ||x|| / 127 (the same for int8 queries)

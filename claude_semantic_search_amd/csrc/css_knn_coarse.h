@@ -1556,7 +1556,8 @@ __global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __
 // Result lane l: query l & 15, rows 4 (l >> 4) .. + 3 of the group; score = acc * row scale * query scale (exact int32
 // accumulation; error band: both operands int8, as in the batch scan).  One launch per cascade stage; thresholds,
 // selects, rescoring and fix-up are the candidate path's.
-template <int KS, bool MAIN>   // KS = dpad / 64 when known at compile time (768: 12), else 0 = run-time steps; MAIN names the stride-1 stage
+// NG = 1: up to 16 queries; NG = 2: up to 32 (two fragment sets, twice the MFMAs per row group: still far from MFMA-bound).
+template <int KS, bool MAIN, int NG = 1>   // KS = dpad / 64 when known at compile time (768: 12), else 0 = run-time steps; MAIN names the stride-1 stage
 __global__ __launch_bounds__(256) void k_sweep_mfma_i8(const unsigned char* __restrict__ x8, const float* __restrict__ x8s,
                                                        const signed char* __restrict__ q8, const float* __restrict__ qsc,
                                                        const float* __restrict__ thr, float* __restrict__ cand_s,
@@ -1567,13 +1568,17 @@ __global__ __launch_bounds__(256) void k_sweep_mfma_i8(const unsigned char* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
     const int ks = KS > 0 ? KS : dpad >> 6;
     constexpr int KSMAX = KS > 0 ? KS : 16;   // (rows of at most 1024 elements carry int8 copies)
-    // this lane's query fragments: rows nq .. 15 of the int8 query block are zeros (k_rows_to_i8)
-    v4i_t qf[KSMAX];
+    // this lane's query fragments (query 16 g + lq): rows nq .. 16 NG - 1 of the int8 query block are zeros (k_rows_to_i8)
+    v4i_t qf[NG][KSMAX];
+    float my_qs[NG], my_thr[NG];
 #pragma unroll
-    for (int t = 0; t < KSMAX; ++t)
-        qf[t] = t < ks ? *reinterpret_cast<const v4i_t*>(q8 + (size_t)lq * dpad + 64 * t + 16 * lg) : v4i_t{0, 0, 0, 0};
-    const float my_qs = lq < nq ? qsc[lq] : 0.f;
-    const float my_thr = (lq < nq && !stage0) ? thr[lq] : INFINITY;
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int t = 0; t < KSMAX; ++t)
+            qf[g][t] = t < ks ? *reinterpret_cast<const v4i_t*>(q8 + (size_t)(16 * g + lq) * dpad + 64 * t + 16 * lg) : v4i_t{0, 0, 0, 0};
+        my_qs[g] = 16 * g + lq < nq ? qsc[16 * g + lq] : 0.f;
+        my_thr[g] = (16 * g + lq < nq && !stage0) ? thr[16 * g + lq] : INFINITY;
+    }
     for (int64_t u = blockIdx.x; u < count; u += gridDim.x) {
         const int64_t tile = (stage0 ? u : u + u / gm1 + 1) * stride;
         const int64_t row_base = tile * CZ_T + wave * 64;
@@ -1592,38 +1597,46 @@ __global__ __launch_bounds__(256) void k_sweep_mfma_i8(const unsigned char* __re
                     a1[t] = v4i_t{(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
                 }
             }
-            v4i_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+            v4i_t c0[NG], c1[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) c0[g] = c1[g] = v4i_t{0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < KSMAX; ++t) {
                 if (t < ks) {
-                    c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], qf[t], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], qf[t], c1, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        c0[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], qf[g][t], c0[g], 0, 0, 0);
+                        c1[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], qf[g][t], c1[g], 0, 0, 0);
+                    }
                 }
             }
-            // lane: query lq, rows R0 .. R0 + 3 (group A) and + 16 (group B)
+            // lane: queries 16 g + lq, rows R0 .. R0 + 3 (group A) and + 16 (group B)
             const int64_t R0 = row_base + 16 * grp + 4 * lg;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int64_t Rh = R0 + 16 * half;
-                const v4i_t c = half ? c1 : c0;
                 float xs[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xs[r] = x8s[Rh + r < ntotal ? Rh + r : ntotal - 1];
-                if (lq < nq) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int qi = 16 * g + lq;
+                    if (qi >= nq) continue;
+                    const v4i_t c = half ? c1[g] : c0[g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = Rh + r;
-                        const float sc = (float)c[r] * xs[r] * my_qs;
+                        const float sc = (float)c[r] * xs[r] * my_qs[g];
                         const bool ok = row < ntotal && CZ_ALLOWED(mask, row);
                         if (stage0) {
-                            const size_t o = (size_t)lq * CZ_CAP + (size_t)u * CZ_T + (size_t)(row - tile * CZ_T);
+                            const size_t o = (size_t)qi * CZ_CAP + (size_t)u * CZ_T + (size_t)(row - tile * CZ_T);
                             cand_s[o] = ok ? sc : -INFINITY;
                             cand_i[o] = ok ? (uint32_t)row : kInvalidRow;
-                        } else if (sc >= my_thr && ok) {
-                            const int slot = atomicAdd(&cand_n[(size_t)lq * CZ_NS], 1);
+                        } else if (sc >= my_thr[g] && ok) {
+                            const int slot = atomicAdd(&cand_n[(size_t)qi * CZ_NS], 1);
                             if (slot < CZ_CAP) {
-                                cand_s[(size_t)lq * CZ_CAP + slot] = sc;
-                                cand_i[(size_t)lq * CZ_CAP + slot] = (uint32_t)row;
+                                cand_s[(size_t)qi * CZ_CAP + slot] = sc;
+                                cand_i[(size_t)qi * CZ_CAP + slot] = (uint32_t)row;
                             }
                         }
                     }

@@ -698,13 +698,13 @@ def test_candidate_path_really_runs_for_both_metrics():
         ix.close()
 
 
-@pytest.mark.parametrize("nq", [3, 7, 12, 16])
+@pytest.mark.parametrize("nq", [3, 7, 12, 16, 17, 32])
 def test_three_to_sixteen_queries_sweep_on_the_int8_mfma(nq):
     """3..16 inner-product queries on an index with int8 rows, from 50 k rows on (k <= 32; 3 and 4 queries reach the
     candidate path from 100 k rows): the cascade stages run on the
     int8 MFMA with the queries as the register operand (k_sweep_mfma_i8; css_index.hip: mfma_sweep_applies) -- the
     reference's search (src/storage.py:429) returns the same ids whatever the batch size, so must this.  The timing
-    scopes show that the path under test is the one that ran; 17 queries go through the batch scan."""
+    scopes show that the path under test is the one that ran; 33 queries go through the batch scan."""
     from oracle import knn_oracle as ko
     from claude_semantic_search_amd import _native as nat
     from claude_semantic_search_amd.flat_index import IndexFlatIP
@@ -715,7 +715,8 @@ def test_three_to_sixteen_queries_sweep_on_the_int8_mfma(nq):
     ix.add(x)
     ref = ko.FlatIndexOracle(d, 0)
     ref.add(x)
-    for count, scope in ((nq, "knn_sweep_mfma_main"), (17, "knn_scan_coarse_main")):
+    # (17 .. 32 queries: two fragment sets per lane; 33 queries go through the batch scan)
+    for count, scope in ((nq, "knn_sweep_mfma_main"), (33, "knn_scan_coarse_main")):
         q = synth.rows(count, d, 42 + count)
         nat.prof_reset()
         nat.prof_enable(True)

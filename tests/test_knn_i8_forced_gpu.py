@@ -17,8 +17,10 @@ def test_parity_suite_with_the_int8_scan_forced():
     columns) and once with CSS_KNN_QREG=0, which keeps every stage on k_scan_coarse8 (what other row widths use)."""
     for qreg, qmin in (("1", "1024"), ("1", "0"), ("0", "1024")):   # (CSS_KNN_QREG_MIN=0: also the stages of a few tiles, and 16 query tiles)
         env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg, CSS_KNN_QREG_MIN=qmin)
+        # (the third pass only re-runs what reaches the batch scan)
+        subset = ["-k", "batch or query_counts or masked or widths or sixteen or coarse or chunks"] if qmin == "0" else []
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                            "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+                            "-p", "no:cacheprovider"] + subset, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
         assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SCAN=i8 CSS_KNN_QREG={qreg} CSS_KNN_QREG_MIN={qmin} failed:\n{tail}\n{r.stderr[-2000:]}"
         assert " passed" in tail
@@ -55,8 +57,8 @@ def test_one_launch_cascade_that_gives_up_still_answers_exactly():
 
 @pytest.mark.gpu
 def test_parity_suite_with_the_int8_mfma_sweep_forced():
-    """3..16 inner-product queries take the int8-MFMA sweep (k_sweep_mfma_i8) by themselves only from 50 k rows on (k <= 32;
-    above: from 1 M rows -- css_index.hip: mfma_sweep_applies); CSS_KNN_SWEEP_MFMA=2 sends every such search of the parity
+    """3..32 inner-product queries take the int8-MFMA sweep (k_sweep_mfma_i8) by themselves only from 50 k rows on (k <= 32;
+    above: from 1 M rows; 17..32 queries: 50 k .. 4 M rows, k > 32 from 2 M rows -- css_index.hip: mfma_sweep_applies); CSS_KNN_SWEEP_MFMA=2 sends every such search of the parity
     suite through it -- tiny and ragged indexes, masks, id bases, duplicates, k = 100 -- and CSS_KNN_SWEEP_MFMA=0 keeps
     what it replaces under the same tests."""
     for mode in ("2", "0"):

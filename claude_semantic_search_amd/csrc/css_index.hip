@@ -1553,7 +1553,7 @@ struct KnnEnv {
     int sweep_fused = 1;    // CSS_KNN_SWEEP_FUSED=0 / 2: the 1..4-query cascade never / always as ONE launch (k_sweep_cascade); 1 = where it pays
     int qreg = 1;           // CSS_KNN_QREG=0: the int8 batch scan's later stages on k_scan_coarse8 instead of k_scan_qreg_i8 (A/B runs)
     int qreg_min = 1024;    // CSS_KNN_QREG_MIN=<tile tasks>: stages with fewer (row tile, query tile) pairs stay on k_scan_coarse8 (two per block: measured, launch_scan_coarse)
-    int sweep_mfma = 1;     // CSS_KNN_SWEEP_MFMA=0: 3..16 queries never take the int8-MFMA sweep (A/B runs); 2: at every index size (tests)
+    int sweep_mfma = 1;     // CSS_KNN_SWEEP_MFMA=0: 3..32 queries never take the int8-MFMA sweep (A/B runs); 2: at every index size (tests)
     int sweep_maxq = -1;    // CSS_KNN_SWEEP_MAXQ=n: searches of up to n (0..4) queries take the sweep cascade (A/B runs); -1 = by size
     int fs_spins = CZ_FS_SPINS;   // CSS_KNN_FS_SPINS=n: polls before a waiting wave of k_sweep_cascade gives up (tests: 0 = at once)
     int fs_blocks = 0;      // CSS_KNN_FS_BLOCKS=n: at most n blocks of k_sweep_cascade per CU (A/B runs); 0 = what fits
@@ -2013,7 +2013,7 @@ inline bool mfma_sweep_applies(const css_index* ix, int64_t nq, int k) {
     return ix->ntotal >= (k <= 32 ? 50000 : 1000000);
 }
 
-// one cascade stage of the int8 MFMA sweep (3..16 queries: k_sweep_mfma_i8); the int8 queries sit in ix->qh
+// one cascade stage of the int8 MFMA sweep (3..32 queries: k_sweep_mfma_i8); the int8 queries sit in ix->qh
 int launch_sweep_mfma(css_index* ix, int nq, int64_t count, int64_t stride, int gm1, bool stage0, hipStream_t st) {
     const int grid = (int)std::min<int64_t>((int64_t)ix->num_cus * 8, count);
     const bool main_stage = stride == 1 && !stage0;
@@ -2122,7 +2122,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     const float* qnorm2 = ix->qnorm2 + q0;
     D_dev += (size_t)q0 * k;
     I_dev += (size_t)q0 * k;
-    // 3..16 queries on int8 rows (inner product): the sweep on the int8 MFMA (k_sweep_mfma_i8): int8 queries too
+    // 3..32 queries on int8 rows (inner product): the sweep on the int8 MFMA (k_sweep_mfma_i8): int8 queries too
     const bool sweep_mfma = sweep && use_i8 && mfma_sweep_applies(ix, nq, k);
     const int nq_pad = sweep ? (sweep_mfma ? (nq <= 16 ? 16 : 32) : nq) : (nq + CZ_T - 1) / CZ_T * CZ_T;
     const int nqt = sweep ? 1 : nq_pad / CZ_T;
@@ -2194,7 +2194,7 @@ int launch_scan_coarse(css_index* ix, int q0, int nq, int k, float* D_dev, int64
     // g = 16 overflows the 4096-slot buffers (~k g candidates per stage) and lands in the exact fix-up: 10 ms.
     const int64_t ntiles = (ix->ntotal + CZ_T - 1) / CZ_T;
     // (int8 scan: its band is ~4 x wider, growth 8 would append ~2500 rows per query in the main stage)
-    // (3..16 queries on the int8 MFMA: one launch per stage, so below ~4 M rows fewer, larger stages win -- ms at growth 4 / 8,
+    // (3..32 queries on the int8 MFMA: one launch per stage, so below ~4 M rows fewer, larger stages win -- ms at growth 4 / 8,
     // k = 10: 1 M rows 0.33 / 0.27, 100 k rows 0.13 / 0.10, 10 M rows 1.59 / 1.55-1.67; k = 100 overflows the buffers at
     // growth 8 and 10 M rows, as the VALU sweep did)
     const int g_sweep = env.growth_sweep ? env.growth_sweep : ((sweep_mfma && k <= 32 && ix->ntotal < 4000000) ? 8 : 4);

@@ -139,7 +139,7 @@ constexpr int CZ_EXK = 256;
 // Band rescoring (k_rescore_parts): a band is split over at most CZ_PARTS blocks
 constexpr int CZ_PARTS = 16;
 // Spacing of the per-query candidate counters, in ints: a 128-byte line each.  The batch scan, which adds once per
-// (row tile, query) with a count, measured no difference to packed counters; the int8 MFMA sweep of 3..16 queries adds
+// (row tile, query) with a count, measured no difference to packed counters; the int8 MFMA sweep of 3..32 queries adds
 // once per hit and lane, and with all sixteen counters on one line its appends queued up behind each other (1 M rows,
 // 16 queries, k = 100: 0.89 ms packed, 0.54 ms a line apart; 4 KB apart: the same).
 #ifndef CZ_NS_STRIDE
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_sweep_coarse_i8(const unsigned char* __
     }
 }
 
-// ------------------------------------------------------------------ 3..16 queries: the sweep on the int8 MFMA
+// ------------------------------------------------------------------ 3..32 queries: the sweep on the int8 MFMA
 // The VALU sweep above costs one fp32 multiply-add per element and QUERY: four queries are VALU-bound (2.65 ms at
 // 10 M rows), and up to 32 queries went through the 256-query tiles of the batch scan, whose LDS-DMA ring re-fetches the
 // query tile for every row tile (1.95-2.0 ms).  Here the (up to 16) int8 queries sit in registers as the B operand

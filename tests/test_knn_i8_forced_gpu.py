@@ -9,6 +9,9 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+# the passes that keep a REPLACED path under test (switch = "0") leave out the cases whose cost is the CPU oracle and
+# whose GPU side the other passes already run: 100 k rows x 1000 queries, 40 k rows x 4200 queries, k beyond one pass
+LIGHT = ["-k", "not config2 and not sixteen_query_tiles and not beyond_one_kernel_pass and not two_host_threads"]
 
 
 @pytest.mark.gpu
@@ -18,7 +21,7 @@ def test_parity_suite_with_the_int8_scan_forced():
     for qreg, qmin in (("1", "1024"), ("1", "0"), ("0", "1024")):   # (CSS_KNN_QREG_MIN=0: also the stages of a few tiles, and 16 query tiles)
         env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg, CSS_KNN_QREG_MIN=qmin)
         # (the third pass only re-runs what reaches the batch scan)
-        subset = ["-k", "batch or query_counts or masked or widths or sixteen or coarse or chunks"] if qmin == "0" else []
+        subset = ["-k", "batch or query_counts or masked or widths or sixteen or coarse or chunks"] if qmin == "0" else (LIGHT if qreg == "0" else [])
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
                             "-p", "no:cacheprovider"] + subset, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
@@ -35,7 +38,8 @@ def test_parity_suite_with_the_one_launch_cascade_forced():
     for mode in ("2", "0"):
         env = dict(os.environ, CSS_KNN_SWEEP_FUSED=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                            "-p", "no:cacheprovider"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+                            "-p", "no:cacheprovider"] + (LIGHT if mode == "0" else []), cwd=str(ROOT), env=env,
+                           capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
         assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SWEEP_FUSED={mode} failed:\n{tail}\n{r.stderr[-2000:]}"
         assert " passed" in tail
@@ -64,7 +68,7 @@ def test_parity_suite_with_the_int8_mfma_sweep_forced():
     for mode in ("2", "0"):
         env = dict(os.environ, CSS_KNN_SWEEP_MFMA=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                            "-p", "no:cacheprovider", "--deselect",
+                            "-p", "no:cacheprovider"] + (LIGHT if mode == "0" else []) + ["--deselect",
                             "tests/test_knn_gpu.py::test_three_to_sixteen_queries_sweep_on_the_int8_mfma"],
                            cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])

@@ -12,16 +12,21 @@ ROOT = Path(__file__).resolve().parent.parent
 # the passes that keep a REPLACED path under test (switch = "0") leave out the cases whose cost is the CPU oracle and
 # whose GPU side the other passes already run: 100 k rows x 1000 queries, 40 k rows x 4200 queries, k beyond one pass
 LIGHT = ["-k", "not config2 and not sixteen_query_tiles and not beyond_one_kernel_pass and not two_host_threads"]
+# the passes that force a FEW-QUERY path leave out what only batches reach
+FEWQ = ["-k", "not config2_100k_768_1000 and not sixteen_query_tiles and not mfma_batch and not no_shadow and not query_chunks "
+        "and not two_host_threads and not many_flagged and not searches_of_one_index and not row_widths and not error_band"]
 
 
 @pytest.mark.gpu
 def test_parity_suite_with_the_int8_scan_forced():
-    """... once with the later stages on k_scan_qreg_i8 (queries resident in registers: rows of 256 / 512 / 768 padded
+    """... once with every later stage on k_scan_qreg_i8 (queries resident in registers: rows of 256 / 512 / 768 padded
     columns) and once with CSS_KNN_QREG=0, which keeps every stage on k_scan_coarse8 (what other row widths use)."""
-    for qreg, qmin in (("1", "1024"), ("1", "0"), ("0", "1024")):   # (CSS_KNN_QREG_MIN=0: also the stages of a few tiles, and 16 query tiles)
+    # (CSS_KNN_QREG_MIN=0: EVERY later stage on k_scan_qreg_i8, also those of a few tiles; the mix with k_scan_coarse8 that
+    # the default minimum gives is what tests/test_fullsize_gpu.py and the bench's self-check run)
+    for qreg, qmin in (("1", "0"), ("0", "1024")):
         env = dict(os.environ, CSS_KNN_SCAN="i8", CSS_KNN_QREG=qreg, CSS_KNN_QREG_MIN=qmin)
         # (the third pass only re-runs what reaches the batch scan)
-        subset = ["-k", "batch or query_counts or masked or widths or sixteen or coarse or chunks"] if qmin == "0" else (LIGHT if qreg == "0" else [])
+        subset = LIGHT if qreg == "0" else []
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
                             "-p", "no:cacheprovider"] + subset, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
@@ -38,7 +43,7 @@ def test_parity_suite_with_the_one_launch_cascade_forced():
     for mode in ("2", "0"):
         env = dict(os.environ, CSS_KNN_SWEEP_FUSED=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                            "-p", "no:cacheprovider"] + (LIGHT if mode == "0" else []), cwd=str(ROOT), env=env,
+                            "-p", "no:cacheprovider"] + FEWQ, cwd=str(ROOT), env=env,
                            capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])
         assert r.returncode == 0, f"test_knn_gpu.py under CSS_KNN_SWEEP_FUSED={mode} failed:\n{tail}\n{r.stderr[-2000:]}"
@@ -68,7 +73,7 @@ def test_parity_suite_with_the_int8_mfma_sweep_forced():
     for mode in ("2", "0"):
         env = dict(os.environ, CSS_KNN_SWEEP_MFMA=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_knn_gpu.py"), "-q", "-x", "-m", "gpu",
-                            "-p", "no:cacheprovider"] + (LIGHT if mode == "0" else []) + ["--deselect",
+                            "-p", "no:cacheprovider"] + FEWQ + ["--deselect",
                             "tests/test_knn_gpu.py::test_three_to_sixteen_queries_sweep_on_the_int8_mfma"],
                            cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
         tail = "\n".join(r.stdout.splitlines()[-15:])

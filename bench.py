@@ -62,7 +62,7 @@ INT8_MFMA_PEAK_TF = 5000.0   # dense int8 MFMA peak (MI355X_MICROARCH.md: the cy
 
 
 def batch_scan_is_int8(index, k: int, rows: int, dim: int) -> bool:
-    """Mirror of css_index.hip batch_i8_wanted (without its nq >= 256 condition for k > 32: the bench batch is 1000 queries): which shadow rows the batched candidate scan reads."""
+    """Mirror of css_index.hip batch_i8_wanted: which shadow rows the batched candidate scan reads."""
     env = os.environ.get("CSS_KNN_SCAN", "")
     if env == "bf16" or not hasattr(index, "shadow_info") or not index.shadow_info().get("int8"):
         return False

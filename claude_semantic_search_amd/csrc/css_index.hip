@@ -1974,7 +1974,10 @@ inline bool batch_i8_wanted(css_index* ix, int k, int64_t rows, int64_t nq) {
     // (round 4, later stages on k_scan_qreg_i8, ms int8 / bf16: k = 100, 1000 queries: 4 M rows 4.1 / 6.1, 2 M 2.7 / 3.3, 1 M 2.0 /
     // 2.0, 300 k 1.3 / 0.9; 256 queries: 2 M 1.0 / 1.4, 1 M 0.87 / 0.75.  k = 10: 1 M 1.04 / 1.57, 300 k 0.53 / 0.64 (256 queries
     // 0.31 / 0.31), 100 k 0.35 / 0.31)
-    const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 2000000 && nq >= 256);
+    // (fewer than 256 queries, k = 100, ms int8 / bf16, 33 / 64 / 128 / 255 queries: 10 M rows 1.89 / 3.19, 2.08 / 3.33, 2.19 /
+    // 3.45, 2.50 / 3.87; 2 M rows 0.73 / 0.82 .. 0.99 / 1.08: the query count is no condition any more)
+    (void)nq;
+    const bool pays = k <= 32 ? rows >= 300000 : (k * 2 <= CZ_EXK && rows >= 2000000);
     if (!pays) return false;
     // (with <= 256 flagged queries the second pass is one query tile of bf16 scan -- a quarter of a 1000-query bf16 step --
     // and the int8 search still wins: 10 M rows in 20 000 clusters, 33 flagged: 12.8 ms against 13.3 on bf16 rows)
@@ -2009,7 +2012,9 @@ inline bool mfma_sweep_applies(const css_index* ix, int64_t nq, int k) {
     // 17..32 queries (two fragment sets per lane), ms with / without: k = 10: 10 M rows 1.78 / 1.66 (the batch scan with the
     // queries in registers is ahead there), 1 M rows 0.33 / 0.38, 100 k rows 0.13 / 0.155; k = 100: 10 M rows 2.0 / 3.2-3.3
     // (the bf16 scan: fewer than 256 queries), 1 M rows 0.56-0.59 / 0.53
-    if (nq > 16) return k <= 32 ? (ix->ntotal >= 50000 && ix->ntotal < 4000000) : ix->ntotal >= 2000000;
+    // (k = 100 at 10 M rows was measured against the bf16 scan; the int8 batch scan, which such a search takes since, is at
+    // 1.89 ms for 33 queries: the sweep stays with k <= 32)
+    if (nq > 16) return k <= 32 && ix->ntotal >= 50000 && ix->ntotal < 4000000;
     return ix->ntotal >= (k <= 32 ? 50000 : 1000000);
 }
 

@@ -96,8 +96,7 @@ int css_index_last_swept(css_index* ix, int64_t* n);
  *   +25 %; rows of at most 1024 elements).  Searches of 1..4 queries sweep the int8 rows (one query: the whole stage
  *   cascade in one persistent kernel launch, css_knn_coarse.h: k_sweep_cascade), 3..32 inner-product queries sweep them on
  *   the int8 MFMA with the queries as the register operand (k_sweep_mfma_i8); batches scan them with int8
- *   MFMA (rows of 256 / 512 / 768 elements: the queries resident in registers, k_scan_qreg_i8) where that pays (inner product, rows a multiple of 256 elements: k <= 32 from 300 k rows, k <= 128 from 2 M rows
- *   with >= 256 queries; an index whose int8 searches flag more than 5 % of their queries falls back to the bf16 rows
+ *   MFMA (rows of 256 / 512 / 768 elements: the queries resident in registers, k_scan_qreg_i8) where that pays (inner product, rows a multiple of 256 elements: k <= 32 from 300 k rows, k <= 128 from 2 M rows; an index whose int8 searches flag more than 5 % of their queries falls back to the bf16 rows
  *   for the next 16 searches), otherwise the bf16 rows.
  * policy: -1 = automatic -- both copies while 7 bytes per element fit in 80 % of the HBM, bf16 only at 6 bytes, INT8 ONLY
  * at 5 bytes (inner product, rows a multiple of 256 elements: ~38-46 M rows of 768 floats on a 288 GB GPU), nothing

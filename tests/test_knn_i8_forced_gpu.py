@@ -1,5 +1,5 @@
-"""The int8 MFMA scan of batches is chosen by itself only from 300 k rows on (k <= 32; k <= 128: from 2 M rows with >= 256
-queries -- css_index.hip: batch_i8_wanted), so the small-index parity suite would hardly reach it: run that whole suite once more in a child process with
+"""The int8 MFMA scan of batches is chosen by itself only from 300 k rows on (k <= 32; k <= 128: from 2 M rows
+-- css_index.hip: batch_i8_wanted), so the small-index parity suite would hardly reach it: run that whole suite once more in a child process with
 CSS_KNN_SCAN=i8 (the switch is read once per process), every batched inner-product search of it on the int8 rows."""
 import os
 import subprocess
